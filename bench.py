@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py - the reference's headline metric on its headline config, on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one pass of the hot path - ``DeepVIO.forward(img, imu, timestamps)`` (reference
+src/models/DeepVIO.py:61-68) - over one synthetic KITTI-shaped batch already resident in HBM:
+BASELINE.json configs[1] = 16 sequences x 11 frames of 256x512, ODEFunc hidden 512, RK4, fp32.
+With N GPUs every rank runs its own 16 sequences (sequences are independent end to end; weak
+scaling) and the per-sequence poses are all-gathered with RCCL inside the timed step.
+
+One JSON line on stdout (rank 0).  ``value`` = frames/s of the whole job; the integrator part of
+the metric is reported beside it (``integrator``), together with
+
+* ``roofline``      - the dominant kernel by time (the fp32-MFMA implicit-GEMM convolution, conv2..conv6),
+                      timed with HIP events on the launch stream inside the timed region,
+* ``roofline_integrator`` - the persistent ODE-RNN kernel against its algorithmic bytes,
+* ``cpu_baseline``  - the oracle (a restatement of the reference's CPU path, same ATen kernels) timed on this
+                      box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from odevio_amd import default_opt, synth, weights  # noqa: E402
+
+METRIC = "ODE integrator steps/s (hidden=512, RK4) + frames/s on KITTI seq-len 11"
+B, S, H, W = 16, 11, 256, 512
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops_per_pair():
+    """Algorithmic FLOPs of conv2..conv6 for one frame pair."""
+    h, w = H, W
+    total = 0
+    for name, cin, cout, k, s in weights.IMAGE_CONVS:
+        h, w = weights.conv_out(h, k, s), weights.conv_out(w, k, s)
+        if name != "conv1":
+            total += 2 * h * w * cout * cin * k * k
+    return total
+
+
+def ode_bytes_per_rk4_step(opt, rows):
+    """4 stages x ODEFunc parameters + state read + write."""
+    F = opt.v_f_len + opt.i_f_len
+    dims = [F] + [opt.ode_hidden_dim] * opt.ode_fn_num_layers + [F]
+    params = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
+    return 4 * params * 4 + 2 * rows * F * 4
+
+
+def cpu_baseline(opt, sd, budget_s=20.0):
+    from oracle import odevio_oracle as oc  # the oracle is the CPU baseline leg, nothing else
+    nb = 1
+    img, imu, ts = synth.batch(nb, S, H, W, seed=1)
+    with torch.no_grad():
+        oc.deepvio_forward(sd, img, imu, ts, None, opt)  # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            oc.deepvio_forward(sd, img, imu, ts, None, opt)
+            reps += 1
+            if time.perf_counter() - t0 > budget_s or reps >= 8:
+                break
+        dt = (time.perf_counter() - t0) / reps
+        # bare RK4 step loop of the [32,768] state (the "integrator steps/s" half of the metric)
+        F = opt.v_f_len + opt.i_f_len
+        y = torch.randn(2 * B, F) * 0.5
+        f = lambda v: oc.ode_func(sd, v, opt.ode_fn_num_layers, opt.ode_activation_fn)
+        h = torch.full((2 * B,), 0.1)
+        oc.rk_stages(f, oc.RK4_38, y, h)
+        t1 = time.perf_counter()
+        n = 200
+        for _ in range(n):
+            y, _, _ = oc.rk_stages(f, oc.RK4_38, y, h)
+        step_s = (time.perf_counter() - t1) / n
+    return {"value": nb * S / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle DeepVIO.forward, {nb} sequence x {S} frames 256x512 fp32, {reps} reps, {dt:.2f} s each",
+            "integrator_steps_per_s": 1.0 / step_s,
+            "integrator_sample": f"{n} RK4 (3/8) steps of the [32,768] state through ODEFunc(768-512-512-512-768)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+
+    from odevio_amd import DeepVIO
+    opt = default_opt(ode_solver="rk4")
+    model = DeepVIO(opt, seed=0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    img, imu, ts = synth.batch(B, S, H, W, seed=100 + rank)
+    img, imu, ts = img.cuda(), imu.cuda(), ts.cuda()
+    gathered = torch.empty(world * B, S - 1, 6, device="cuda") if world > 1 else None
+
+    def step():
+        poses, h_T = model(img, imu, ts)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, poses)  # per-sequence poses to every rank
+        return poses
+
+    for _ in range(args.warmup):
+        step()
+    model.check()
+    model.profile_enable(True)
+    stage_ms = {k: 0.0 for k in model.STAGES}
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # reading the events waits for this step only; the next launch queue is refilled immediately
+        for k, v in model.profile_read().items():
+            stage_ms[k] += v
+    sync()
+    elapsed = time.perf_counter() - t0
+    model.check()
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for k in stage_ms:
+        stage_ms[k] /= args.steps
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        frames_per_s = world * B * S * args.steps / elapsed
+        P = B * (S - 1)
+        conv_tflops = conv_flops_per_pair() * P / (stage_ms["conv2_6"] * 1e-3) / 1e12
+        rows = opt.rnn_num_layers * B
+        n_rk4 = (S - 1) * opt.ode_substeps
+        integ_s = stage_ms["integrator"] * 1e-3
+        integ_bytes = ode_bytes_per_rk4_step(opt, rows) * n_rk4
+        out = {
+            "metric": METRIC, "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DeepVIO.forward: {B} sequences x {S} frames 256x512 per GPU, ODEFunc 768-512-512-512-768, "
+                                   f"RK4 (3/8) 1 step/interval, 2-layer tanh RNN, fp32 (BASELINE configs[1])",
+                       "sequences_per_gpu": B, "seq_len": S, "ode_solver": "rk4", "sharding": f"sequences x{world}"},
+            "integrator": {"steps_per_s": round(n_rk4 / integ_s, 1), "rows": rows, "unit": "RK4 steps/s of the [32,768] state, inside the ODE-RNN loop (RNN cell included)",
+                           "ms_per_forward": round(stage_ms["integrator"], 4)},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"kernel": "conv_igemm_kernel (conv2..conv6)", "bound": "mfma", "achieved": round(conv_tflops, 2),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None},
+            "roofline_integrator": {"kernel": "integrator_kernel", "bound": "hbm",
+                                    "achieved": round(integ_bytes / integ_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(integ_bytes / integ_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                                    "note": "latency-bound by design: weights stay in LDS, algorithmic bytes assume a re-read per stage"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(opt, sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

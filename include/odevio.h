@@ -1,0 +1,140 @@
+/*
+ * odevio.h - C ABI of libodevio.so: the MI355X (gfx950) implementation of the ODE-VIO hot path.
+ *
+ * The reference (mc1017/ODE-VIO) is 100% Python and has no FFI layer of its own; the drop-in
+ * boundary is its Python class surface, DeepVIO(opt).forward(img, imu, timestamps, hc)
+ * (reference src/models/DeepVIO.py:37-68).  This header is the C boundary placed directly UNDER
+ * that surface: each entry point replaces one reference method and is what a maintainer would bind
+ * from the reference's Python (ctypes stub in INTEGRATION.md).  Plain pointers and sizes only - no
+ * torch types.  All tensor pointers are DEVICE pointers to contiguous fp32 unless stated; `stream`
+ * is a hipStream_t passed as void* (NULL = the null stream).  The library never allocates or frees
+ * caller tensors; it owns only the opaque plan (re-laid-out weights + activation workspace).
+ *
+ * Error convention: every function returns 0 on success and a negative odevio_status otherwise;
+ * odevio_last_error() gives a thread-local message.  The Python host maps
+ * ODEVIO_ERR_UNSUPPORTED/BAD_ARG to ValueError like the reference's own constructors
+ * (reference src/models/PoseODERNN.py:136,146; src/models/ODEFunc.py:34).
+ *
+ * Threading: a plan is not re-entrant (one forward at a time per plan); different plans are
+ * independent.  No internal threads.  Nothing synchronises the stream except odevio_plan_create
+ * (weight re-layout), odevio_reserve and odevio_check.
+ */
+#ifndef ODEVIO_H
+#define ODEVIO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODEVIO_VERSION 1
+
+typedef struct odevio_plan odevio_plan;
+
+enum odevio_status {
+  ODEVIO_OK = 0,
+  ODEVIO_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, unknown enum              */
+  ODEVIO_ERR_UNSUPPORTED = -2,  /* valid request the kernels do not cover (dimension rules)   */
+  ODEVIO_ERR_MISSING_WEIGHT = -3,
+  ODEVIO_ERR_HIP = -4,          /* a HIP runtime call failed                                  */
+  ODEVIO_ERR_NO_DEVICE = -5,
+  ODEVIO_ERR_TIMEOUT = -6,      /* a bounded in-kernel wait gave up (reported by odevio_check)*/
+  ODEVIO_ERR_MAX_STEPS = -7     /* adaptive solver exceeded max_steps (reported by check)     */
+};
+
+/* reference src/models/ODEFunc.py:23-36 */
+enum odevio_activation { ODEVIO_ACT_TANH = 0, ODEVIO_ACT_RELU = 1, ODEVIO_ACT_LEAKY_RELU = 2, ODEVIO_ACT_SOFTPLUS = 3 };
+/* reference src/models/PoseODERNN.py:125-137 (first four); RK4 variants are BASELINE extensions */
+enum odevio_solver { ODEVIO_DOPRI5 = 0, ODEVIO_HEUN = 1, ODEVIO_TSIT5 = 2, ODEVIO_EULER = 3, ODEVIO_RK4 = 4, ODEVIO_RK4_CLASSIC = 5 };
+/* reference src/models/PoseODERNN.py:139-148 */
+enum odevio_rnn { ODEVIO_RNN_TANH = 0, ODEVIO_RNN_GRU = 1 };
+/* reference src/models/FusionModule.py:17-23 ("hard" is stochastic: host-side only) */
+enum odevio_fuse { ODEVIO_FUSE_CAT = 0, ODEVIO_FUSE_SOFT = 1 };
+/* reference src/models/DeepVIO.py:45-59 */
+enum odevio_model { ODEVIO_MODEL_ODE_RNN = 0, ODEVIO_MODEL_RNN = 1, ODEVIO_MODEL_CDE = 2 };
+
+/* The hot-path subset of reference scripts/config.py:29,48-51,59,62-65,68-69 + controller constants
+ * of reference src/models/PoseODERNN.py:57,72 (torchode IntegralController(atol, rtol), dt0). */
+typedef struct odevio_config {
+  int32_t struct_size; /* = sizeof(odevio_config), ABI guard */
+  int32_t model_type;  /* odevio_model */
+  int32_t img_h, img_w;
+  int32_t v_f_len, i_f_len;
+  int32_t fuse_method;        /* odevio_fuse */
+  int32_t ode_hidden_dim;     /* width H of the ODEFunc MLP */
+  int32_t ode_fn_num_layers;  /* n: ODEFunc has n+1 Linears */
+  int32_t ode_activation;     /* odevio_activation */
+  int32_t ode_solver;         /* odevio_solver */
+  int32_t ode_substeps;       /* fixed-step solvers: equal sub-steps per interval (>=1) */
+  int32_t rnn_type;           /* odevio_rnn */
+  int32_t rnn_num_layers;
+  float atol, rtol, dt0;      /* 1e-6, 1e-2, 1e-4 in the reference */
+  int32_t max_steps;          /* per-interval step budget of the adaptive solvers */
+} odevio_config;
+
+/* One named weight, keyed exactly like the reference state_dict, fp32 on device. */
+typedef struct odevio_tensor {
+  const char* name;
+  const void* data;
+  int64_t numel;
+} odevio_tensor;
+
+/* Per-row integrator statistics written by odevio_ode_rnn_fwd / odevio_ode_steps when `stats` != NULL:
+ * stats[2*row+0] = steps attempted, stats[2*row+1] = steps accepted (summed over intervals). */
+
+int odevio_version(void);
+const char* odevio_last_error(void);
+
+/* Builds a plan: validates the config, finds every weight by name, folds BatchNorm running stats
+ * into per-channel (scale, shift), re-lays convolution weights as [Cout][kh][kw][Cin], permutes the
+ * visual head to the NHWC flatten order and column-shards the ODEFunc/RNN weights for the
+ * persistent integrator.  Replaces: DeepVIO.__init__ + load_state_dict (DeepVIO.py:37-43). */
+int odevio_plan_create(const odevio_config* cfg, const odevio_tensor* weights, int32_t n_weights, void* stream,
+                       odevio_plan** out_plan);
+void odevio_plan_destroy(odevio_plan* plan);
+/* Pre-allocates the activation workspace for batches up to (B, S) so that later calls allocate nothing. */
+int odevio_reserve(odevio_plan* plan, int32_t B, int32_t S, void* stream);
+/* Synchronises `stream` and returns the device status word of the last integrator launch. */
+int odevio_check(odevio_plan* plan, void* stream);
+
+/* ImageEncoder.forward (Encoder.py:97-122): img [B,S,3,H,W] -> fv [B,S-1,v_f_len] with row stride ld_fv. */
+int odevio_image_encoder_fwd(odevio_plan* plan, const float* img, int32_t B, int32_t S, float* fv, int32_t ld_fv,
+                             void* stream);
+/* One Conv2d+BatchNorm2d+LeakyReLU block of the ImageEncoder (Encoder.py:8-22), for kernel-level
+ * parity tests: layer 0 (conv1) reads img [B,S,3,H,W] and writes NHWC [B*(S-1),H/2,W/2,64]; layer i>0 reads the
+ * NHWC output of layer i-1 for `pairs` frame pairs and writes its own NHWC output. */
+int odevio_conv_block_fwd(odevio_plan* plan, int32_t layer, const float* in, int32_t B, int32_t S, float* out,
+                          void* stream);
+/* InertialEncoder.forward (Encoder.py:60-74): imu [B,T,6] -> fi [B,(T-1)/10,i_f_len] with row stride ld_fi. */
+int odevio_imu_encoder_fwd(odevio_plan* plan, const float* imu, int32_t B, int32_t T, float* fi, int32_t ld_fi,
+                           void* stream);
+/* FusionModule.forward (FusionModule.py:17-23): fv [P,v], fi [P,i] -> fused [P,v+i]. */
+int odevio_fuse_fwd(odevio_plan* plan, const float* fv, const float* fi, int32_t P, float* fused, void* stream);
+/* ODEFunc.forward (ODEFunc.py:38-39): y [rows,F] -> f(y) [rows,F]. */
+int odevio_ode_func(odevio_plan* plan, const float* y, int32_t rows, float* out, void* stream);
+/* PoseODERNN.evolve_state (PoseODERNN.py:70-75): integrate rows from t0[r] to t1[r].
+ * solver < 0 uses the plan's; substeps <= 0 uses the plan's. */
+int odevio_ode_steps(odevio_plan* plan, const float* y, const float* t0, const float* t1, int32_t rows,
+                     int32_t solver, int32_t substeps, float* y_out, int32_t* stats, void* stream);
+/* PoseODERNN.forward / PoseRNN.forward (PoseODERNN.py:88-123) AFTER fusion:
+ * fused [B,P,F], ts [B,P+1], hc_in NULL or [L,B,F] -> poses [B,P,6], h_T [L,B,F]. */
+int odevio_ode_rnn_fwd(odevio_plan* plan, const float* fused, const float* ts, const float* hc_in, int32_t B,
+                       int32_t P, float* poses, float* h_T, int32_t* stats, void* stream);
+/* DeepVIO.forward (DeepVIO.py:61-68): img [B,S,3,H,W], imu [B,T,6], ts [B,S], hc NULL or [L,B,F]
+ * -> poses [B,S-1,6], h_T [L,B,F]. */
+int odevio_forward(odevio_plan* plan, const float* img, const float* imu, int32_t T, const float* ts,
+                   const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream);
+
+/* Per-stage timing of odevio_forward with HIP events recorded on the caller's stream (used by bench.py for
+ * the roofline figures).  Stages: 0 conv1, 1 conv2..conv6 (implicit-GEMM kernel), 2 visual head,
+ * 3 inertial encoder + fusion, 4 persistent ODE-RNN integrator, 5 pose regressor. */
+#define ODEVIO_N_STAGES 6
+int odevio_profile_enable(odevio_plan* plan, int32_t on);
+/* Waits for the last recorded forward and writes ODEVIO_N_STAGES durations in milliseconds. */
+int odevio_profile_read(odevio_plan* plan, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODEVIO_H */

@@ -1,0 +1,780 @@
+// C ABI of libodevio.so (include/odevio.h): plan construction (weight re-layout, BatchNorm
+// folding, column-sharding for the persistent integrator), activation workspace, and the launch
+// sequences that replace the reference's DeepVIO.forward (src/models/DeepVIO.py:61-68).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/odevio.h"
+#include "common.h"
+#include "integrator.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess) return fail(ODEVIO_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct ConvSpec {
+  const char* name;
+  int cin, cout, k, stride;
+};
+static const ConvSpec kConvs[9] = {
+    {"conv1", 6, 64, 7, 2},     {"conv2", 64, 128, 5, 2},    {"conv3", 128, 256, 5, 2},
+    {"conv3_1", 256, 256, 3, 1}, {"conv4", 256, 512, 3, 2},   {"conv4_1", 512, 512, 3, 1},
+    {"conv5", 512, 512, 3, 2},   {"conv5_1", 512, 512, 3, 1}, {"conv6", 512, 1024, 3, 2}};
+static int conv_out(int n, int k, int s) { return (n + 2 * ((k - 1) / 2) - k) / s + 1; }
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t n = 0;  // floats
+};
+
+struct odevio_plan {
+  odevio_config cfg;
+  int device = 0, n_cu = 0;
+  int F = 0;
+  // encoder
+  float* conv_w[9] = {};
+  float* conv_scale[9] = {};
+  float* conv_shift[9] = {};
+  int conv_h[10] = {}, conv_w_sp[10] = {};  // spatial size before conv i (index 0 = image)
+  float *head_w = nullptr, *head_b = nullptr;
+  int head_k = 0;
+  float *imu_w[3] = {}, *imu_s[3] = {}, *imu_h[3] = {};
+  float *proj_w = nullptr, *proj_b = nullptr;
+  float *fuse_w = nullptr, *fuse_b = nullptr;
+  float *reg_w0 = nullptr, *reg_b0 = nullptr, *reg_w2 = nullptr, *reg_b2 = nullptr;
+  // integrator
+  int nlin = 0;
+  int dims[INTEG_MAX_LIN + 1] = {};
+  float* ode_w[INTEG_MAX_LIN] = {};
+  float* ode_b[INTEG_MAX_LIN] = {};
+  float* rnn_w[INTEG_MAX_L] = {};
+  float* rnn_b[INTEG_MAX_L] = {};
+  int rnn_vcols = 1;
+  unsigned long long* xbuf = nullptr;
+  int xstride = 0;
+  int* status = nullptr;
+  // workspace (grown on demand)
+  DevBuf actA, actB, imu_act, fcat, fused, out_seq, reg_hid, partial, hT_scratch;
+  std::vector<void*> owned;
+  // optional per-stage HIP-event timing of odevio_forward (bench.py's roofline figures)
+  bool prof = false;
+  hipEvent_t ev[ODEVIO_N_STAGES + 1] = {};
+};
+
+static void stage_mark(odevio_plan* p, int i, hipStream_t st) {
+  if (p->prof) (void)hipEventRecord(p->ev[i], st);
+}
+
+static int dev_alloc(odevio_plan* p, void** out, size_t bytes) {
+  HIPCHK(hipMalloc(out, bytes));
+  p->owned.push_back(*out);
+  return 0;
+}
+static int upload(odevio_plan* p, float** out, const std::vector<float>& h, hipStream_t st) {
+  int rc = dev_alloc(p, (void**)out, h.size() * sizeof(float));
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(*out, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // h may be a temporary
+  return 0;
+}
+static int ensure(DevBuf& b, size_t n) {
+  if (b.n >= n) return 0;
+  if (b.p) HIPCHK(hipFree(b.p));
+  b.p = nullptr;
+  b.n = 0;
+  HIPCHK(hipMalloc((void**)&b.p, n * sizeof(float)));
+  b.n = n;
+  return 0;
+}
+
+struct WeightTable {
+  std::map<std::string, std::pair<const void*, int64_t>> m;
+  hipStream_t st;
+  int get(const std::string& name, int64_t numel, std::vector<float>& out) const {
+    auto it = m.find(name);
+    if (it == m.end()) return fail(ODEVIO_ERR_MISSING_WEIGHT, "weight '%s' not provided", name.c_str());
+    if (it->second.second != numel)
+      return fail(ODEVIO_ERR_BAD_ARG, "weight '%s' has %lld elements, expected %lld", name.c_str(),
+                  (long long)it->second.second, (long long)numel);
+    out.resize((size_t)numel);
+    HIPCHK(hipMemcpyAsync(out.data(), it->second.first, (size_t)numel * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+};
+
+// BatchNorm(eval) as y = x*scale + shift; a preceding conv bias folds into shift.
+static int bn_fold(const WeightTable& wt, const std::string& bn, int c, const std::vector<float>* conv_bias,
+                   std::vector<float>& scale, std::vector<float>& shift) {
+  std::vector<float> g, b, mu, var;
+  int rc;
+  if ((rc = wt.get(bn + ".weight", c, g))) return rc;
+  if ((rc = wt.get(bn + ".bias", c, b))) return rc;
+  if ((rc = wt.get(bn + ".running_mean", c, mu))) return rc;
+  if ((rc = wt.get(bn + ".running_var", c, var))) return rc;
+  scale.resize(c);
+  shift.resize(c);
+  for (int i = 0; i < c; ++i) {
+    const float s = g[i] / std::sqrt(var[i] + 1e-5f);
+    const float cb = conv_bias ? (*conv_bias)[i] : 0.f;
+    scale[i] = s;
+    shift[i] = (cb - mu[i]) * s + b[i];
+  }
+  return 0;
+}
+
+// [N][K] row-major -> per-member slices [member][j][col][ks][4] (integrator.hip, layer()).
+static void shard_columns(const std::vector<float>& W, int N, int K, std::vector<float>& out) {
+  const int NC = N / INTEG_MEMBERS;
+  out.assign((size_t)N * K, 0.f);
+  for (int m = 0; m < INTEG_MEMBERS; ++m)
+    for (int j = 0; j < K / 64; ++j)
+      for (int col = 0; col < NC; ++col)
+        for (int ks = 0; ks < 16; ++ks)
+          for (int e = 0; e < 4; ++e)
+            out[(size_t)m * NC * K + (((size_t)j * NC + col) * 16 + ks) * 4 + e] =
+                W[(size_t)(m * NC + col) * K + j * 64 + ks * 4 + e];
+}
+
+extern "C" int odevio_version(void) { return ODEVIO_VERSION; }
+extern "C" const char* odevio_last_error(void) { return g_err; }
+
+extern "C" void odevio_plan_destroy(odevio_plan* p) {
+  if (!p) return;
+  for (void* q : p->owned) (void)hipFree(q);
+  for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
+                    &p->hT_scratch})
+    if (b->p) (void)hipFree(b->p);
+  delete p;
+}
+
+static int validate(const odevio_config& c) {
+  if (c.struct_size != (int)sizeof(odevio_config)) return fail(ODEVIO_ERR_BAD_ARG, "odevio_config size mismatch");
+  if (c.model_type != ODEVIO_MODEL_ODE_RNN && c.model_type != ODEVIO_MODEL_RNN)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "model_type %d is not built yet (ode-rnn and rnn are)", c.model_type);
+  if (c.img_h < 64 || c.img_w < 64) return fail(ODEVIO_ERR_BAD_ARG, "image size %dx%d too small", c.img_h, c.img_w);
+  if (c.fuse_method != ODEVIO_FUSE_CAT && c.fuse_method != ODEVIO_FUSE_SOFT)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "fuse method %d has no deterministic device path", c.fuse_method);
+  if (c.ode_activation < 0 || c.ode_activation > 3) return fail(ODEVIO_ERR_BAD_ARG, "Activation function not supported");
+  if (c.ode_solver < 0 || c.ode_solver > ODEVIO_RK4_CLASSIC) return fail(ODEVIO_ERR_BAD_ARG, "Solver not supported");
+  if (c.rnn_type != ODEVIO_RNN_TANH && c.rnn_type != ODEVIO_RNN_GRU) return fail(ODEVIO_ERR_BAD_ARG, "RNN type not supported");
+  if (c.rnn_num_layers < 1 || c.rnn_num_layers > INTEG_MAX_L)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "rnn_num_layers must be 1..%d", INTEG_MAX_L);
+  if (c.ode_fn_num_layers < 1 || c.ode_fn_num_layers + 1 > INTEG_MAX_LIN)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "ode_fn_num_layers must be 1..%d", INTEG_MAX_LIN - 1);
+  const int F = c.v_f_len + c.i_f_len;
+  if (F % 64 || F > INTEG_KMAX || c.ode_hidden_dim % 64 || c.ode_hidden_dim > INTEG_KMAX)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "v_f_len+i_f_len (%d) and ode_hidden_dim (%d) must be multiples of 64, at most %d",
+                F, c.ode_hidden_dim, INTEG_KMAX);
+  if (c.v_f_len % 4 || c.i_f_len % 4) return fail(ODEVIO_ERR_UNSUPPORTED, "feature lengths must be multiples of 4");
+  if (c.ode_substeps < 1) return fail(ODEVIO_ERR_BAD_ARG, "ode_substeps must be >= 1");
+  return 0;
+}
+
+extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor* weights, int32_t n_weights,
+                                  void* stream, odevio_plan** out_plan) {
+  if (!cfg || !weights || !out_plan || n_weights <= 0) return fail(ODEVIO_ERR_BAD_ARG, "null argument");
+  int rc = validate(*cfg);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(ODEVIO_ERR_NO_DEVICE, "no HIP device");
+  hipStream_t st = (hipStream_t)stream;
+  odevio_plan* p = new odevio_plan();
+  p->cfg = *cfg;
+  HIPCHK(hipGetDevice(&p->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, p->device));
+  p->n_cu = prop.multiProcessorCount;
+  const int F = cfg->v_f_len + cfg->i_f_len;
+  p->F = F;
+  WeightTable wt;
+  wt.st = st;
+  for (int i = 0; i < n_weights; ++i)
+    if (weights[i].name) wt.m[weights[i].name] = {weights[i].data, weights[i].numel};
+
+#define TRY(x)                 \
+  do {                         \
+    rc = (x);                  \
+    if (rc) {                  \
+      odevio_plan_destroy(p);  \
+      return rc;               \
+    }                          \
+  } while (0)
+
+  std::vector<float> w, t, sc, sh, bias;
+  // ---- image encoder
+  p->conv_h[0] = cfg->img_h;
+  p->conv_w_sp[0] = cfg->img_w;
+  for (int i = 0; i < 9; ++i) {
+    const ConvSpec& cs = kConvs[i];
+    p->conv_h[i + 1] = conv_out(p->conv_h[i], cs.k, cs.stride);
+    p->conv_w_sp[i + 1] = conv_out(p->conv_w_sp[i], cs.k, cs.stride);
+    const std::string pre = std::string("Image_net.") + cs.name;
+    TRY(wt.get(pre + ".0.weight", (int64_t)cs.cout * cs.cin * cs.k * cs.k, w));
+    t.resize(w.size());
+    if (i == 0) {  // [294][64]: k = c*49 + kh*7 + kw
+      for (int n = 0; n < 64; ++n)
+        for (int k = 0; k < 294; ++k) t[(size_t)k * 64 + n] = w[(size_t)n * 294 + k];
+    } else {  // [Cout][Cin][kh][kw] -> [Cout][kh][kw][Cin]
+      const int kk = cs.k * cs.k;
+      for (int n = 0; n < cs.cout; ++n)
+        for (int c = 0; c < cs.cin; ++c)
+          for (int q = 0; q < kk; ++q) t[((size_t)n * kk + q) * cs.cin + c] = w[((size_t)n * cs.cin + c) * kk + q];
+    }
+    TRY(upload(p, &p->conv_w[i], t, st));
+    TRY(bn_fold(wt, pre + ".1", cs.cout, nullptr, sc, sh));
+    TRY(upload(p, &p->conv_scale[i], sc, st));
+    TRY(upload(p, &p->conv_shift[i], sh, st));
+  }
+  {
+    const int oh = p->conv_h[9], ow = p->conv_w_sp[9];
+    p->head_k = 1024 * oh * ow;
+    if (p->head_k % 32) {
+      odevio_plan_destroy(p);
+      return fail(ODEVIO_ERR_UNSUPPORTED, "encoder output size unsupported");
+    }
+    TRY(wt.get("Image_net.visual_head.weight", (int64_t)cfg->v_f_len * p->head_k, w));
+    t.resize(w.size());  // reference flattens (C,H,W); our activations are (H,W,C)
+    for (int n = 0; n < cfg->v_f_len; ++n)
+      for (int c = 0; c < 1024; ++c)
+        for (int s = 0; s < oh * ow; ++s)
+          t[(size_t)n * p->head_k + (size_t)s * 1024 + c] = w[(size_t)n * p->head_k + (size_t)c * oh * ow + s];
+    TRY(upload(p, &p->head_w, t, st));
+    TRY(wt.get("Image_net.visual_head.bias", cfg->v_f_len, bias));
+    TRY(upload(p, &p->head_b, bias, st));
+  }
+  // ---- inertial encoder
+  {
+    const int cin[3] = {6, 64, 128}, cout[3] = {64, 128, 256}, idx[3] = {0, 4, 8};
+    for (int i = 0; i < 3; ++i) {
+      const std::string pre = "Inertial_net.encoder_conv." + std::to_string(idx[i]);
+      TRY(wt.get(pre + ".weight", (int64_t)cout[i] * cin[i] * 3, w));
+      TRY(wt.get(pre + ".bias", cout[i], bias));
+      t.resize(w.size());  // [co][ci][k] -> [(ci,k)][co]
+      for (int co = 0; co < cout[i]; ++co)
+        for (int ci = 0; ci < cin[i]; ++ci)
+          for (int k = 0; k < 3; ++k) t[((size_t)ci * 3 + k) * cout[i] + co] = w[((size_t)co * cin[i] + ci) * 3 + k];
+      TRY(upload(p, &p->imu_w[i], t, st));
+      TRY(bn_fold(wt, "Inertial_net.encoder_conv." + std::to_string(idx[i] + 1), cout[i], &bias, sc, sh));
+      TRY(upload(p, &p->imu_s[i], sc, st));
+      TRY(upload(p, &p->imu_h[i], sh, st));
+    }
+    TRY(wt.get("Inertial_net.proj.weight", (int64_t)cfg->i_f_len * 2816, w));
+    TRY(upload(p, &p->proj_w, w, st));
+    TRY(wt.get("Inertial_net.proj.bias", cfg->i_f_len, bias));
+    TRY(upload(p, &p->proj_b, bias, st));
+  }
+  // ---- fusion, regressor
+  if (cfg->fuse_method == ODEVIO_FUSE_SOFT) {
+    TRY(wt.get("Pose_net.fuse.net.0.weight", (int64_t)F * F, w));
+    TRY(upload(p, &p->fuse_w, w, st));
+    TRY(wt.get("Pose_net.fuse.net.0.bias", F, bias));
+    TRY(upload(p, &p->fuse_b, bias, st));
+  }
+  TRY(wt.get("Pose_net.regressor.0.weight", (int64_t)128 * F, w));
+  TRY(upload(p, &p->reg_w0, w, st));
+  TRY(wt.get("Pose_net.regressor.0.bias", 128, bias));
+  TRY(upload(p, &p->reg_b0, bias, st));
+  TRY(wt.get("Pose_net.regressor.2.weight", (int64_t)6 * 128, w));
+  TRY(upload(p, &p->reg_w2, w, st));
+  TRY(wt.get("Pose_net.regressor.2.bias", 6, bias));
+  TRY(upload(p, &p->reg_b2, bias, st));
+  // ---- ODEFunc (column-sharded)
+  if (cfg->model_type == ODEVIO_MODEL_ODE_RNN) {
+    p->nlin = cfg->ode_fn_num_layers + 1;
+    p->dims[0] = F;
+    for (int l = 1; l < p->nlin; ++l) p->dims[l] = cfg->ode_hidden_dim;
+    p->dims[p->nlin] = F;
+    for (int l = 0; l < p->nlin; ++l) {
+      const std::string pre = "Pose_net.ode_func.net." + std::to_string(2 * l);
+      const int N = p->dims[l + 1], K = p->dims[l];
+      TRY(wt.get(pre + ".weight", (int64_t)N * K, w));
+      shard_columns(w, N, K, t);
+      TRY(upload(p, &p->ode_w[l], t, st));
+      TRY(wt.get(pre + ".bias", N, bias));
+      TRY(upload(p, &p->ode_b[l], bias, st));
+    }
+  }
+  // ---- RNN stack: virtual columns over K = [input | hidden]
+  {
+    const int L = cfg->rnn_num_layers;
+    const bool gru = cfg->rnn_type == ODEVIO_RNN_GRU;
+    const int gates = gru ? 3 : 1;
+    const int V = gru ? 4 : 1;
+    p->rnn_vcols = V;
+    const int NCF = F / INTEG_MEMBERS;
+    std::vector<float> wih, whh, bih, bhh;
+    for (int l = 0; l < L; ++l) {
+      const std::string s = std::to_string(l);
+      TRY(wt.get("Pose_net.rnn.weight_ih_l" + s, (int64_t)gates * F * F, wih));
+      TRY(wt.get("Pose_net.rnn.weight_hh_l" + s, (int64_t)gates * F * F, whh));
+      TRY(wt.get("Pose_net.rnn.bias_ih_l" + s, (int64_t)gates * F, bih));
+      TRY(wt.get("Pose_net.rnn.bias_hh_l" + s, (int64_t)gates * F, bhh));
+      // virtual matrix [V*F][2F], row order: member-major, then v, then local unit
+      std::vector<float> vm((size_t)V * F * 2 * F, 0.f), vb((size_t)V * F, 0.f);
+      for (int m = 0; m < INTEG_MEMBERS; ++m)
+        for (int v = 0; v < V; ++v)
+          for (int ul = 0; ul < NCF; ++ul) {
+            const int u = m * NCF + ul;
+            float* dst = &vm[((size_t)(m * V + v) * NCF + ul) * 2 * F];
+            if (!gru) {
+              memcpy(dst, &wih[(size_t)u * F], F * sizeof(float));
+              memcpy(dst + F, &whh[(size_t)u * F], F * sizeof(float));
+              vb[u] = bih[u] + bhh[u];
+            } else if (v < 2) {  // r, z
+              memcpy(dst, &wih[((size_t)v * F + u) * F], F * sizeof(float));
+              memcpy(dst + F, &whh[((size_t)v * F + u) * F], F * sizeof(float));
+              vb[(size_t)v * F + u] = bih[(size_t)v * F + u] + bhh[(size_t)v * F + u];
+            } else if (v == 2) {  // n, input part
+              memcpy(dst, &wih[((size_t)2 * F + u) * F], F * sizeof(float));
+              vb[(size_t)2 * F + u] = bih[(size_t)2 * F + u];
+            } else {  // n, hidden part
+              memcpy(dst + F, &whh[((size_t)2 * F + u) * F], F * sizeof(float));
+              vb[(size_t)3 * F + u] = bhh[(size_t)2 * F + u];
+            }
+          }
+      shard_columns(vm, V * F, 2 * F, t);
+      TRY(upload(p, &p->rnn_w[l], t, st));
+      TRY(upload(p, &p->rnn_b[l], vb, st));
+    }
+  }
+  // ---- exchange buffers + status
+  p->xstride = 8 * INTEG_KMAX;
+  TRY(dev_alloc(p, (void**)&p->xbuf, (size_t)INTEG_GROUPS * 2 * p->xstride * sizeof(unsigned long long)));
+  TRY(dev_alloc(p, (void**)&p->status, 64));
+  HIPCHK(hipMemsetAsync(p->status, 0, 64, st));
+  HIPCHK(hipStreamSynchronize(st));
+#undef TRY
+  *out_plan = p;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int pick_splitk(int M, int N, int nk) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles >= 192 || nk < 8) return 1;
+  int s = (256 + tiles - 1) / tiles;
+  s = std::min(s, nk / 4);
+  s = std::min(s, 64);
+  return std::max(s, 1);
+}
+
+static int run_gemm(odevio_plan* p, const float* in, int M, int K, const float* W, int N, const float* scale,
+                    const float* shift, const float* mul, int ld_mul, float* out, int ld_out, int act, float slope,
+                    hipStream_t st) {
+  ConvArgs a{};
+  a.in = in; a.w = W; a.scale = scale; a.shift = shift; a.mul = mul; a.out = out;
+  a.N = M; a.Hi = a.Wi = a.Ho = a.Wo = 1; a.Cin = K; a.Cout = N; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
+  a.M = M; a.ld_out = ld_out; a.ld_mul = ld_mul; a.act = act; a.slope = slope;
+  const int nk = K / 32;
+  a.splitk = pick_splitk(M, N, nk);
+  a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
+  a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
+  if (a.splitk > 1) {
+    int rc = ensure(p->partial, (size_t)a.splitk * M * N);
+    if (rc) return rc;
+    a.partial = p->partial.p;
+  }
+  launch_conv_igemm(a, st);
+  return 0;
+}
+
+static int conv_block(odevio_plan* p, int i, const float* in, int B, int S, float* out, hipStream_t st) {
+  const int P = B * (S - 1);
+  const ConvSpec& cs = kConvs[i];
+  if (i == 0) {
+    Conv1Args a{};
+    a.img = in; a.wt = p->conv_w[0]; a.scale = p->conv_scale[0]; a.shift = p->conv_shift[0]; a.out = out;
+    a.B = B; a.S = S; a.H = p->conv_h[0]; a.W = p->conv_w_sp[0]; a.Ho = p->conv_h[1]; a.Wo = p->conv_w_sp[1];
+    a.tiles_y = (a.Ho + 7) / 8; a.tiles_x = (a.Wo + 31) / 32; a.n_tiles = P * a.tiles_y * a.tiles_x; a.slope = 0.1f;
+    launch_conv1(a, p->n_cu, st);
+    return 0;
+  }
+  ConvArgs a{};
+  a.in = in; a.w = p->conv_w[i]; a.scale = p->conv_scale[i]; a.shift = p->conv_shift[i]; a.out = out;
+  a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
+  a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
+  a.M = P * a.Ho * a.Wo; a.ld_out = cs.cout; a.act = EPI_LEAKY; a.slope = 0.1f;
+  const int nk = cs.k * cs.k * cs.cin / 32;
+  a.splitk = pick_splitk(a.M, a.Cout, nk);
+  a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
+  a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
+  if (a.splitk > 1) {
+    int rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout);
+    if (rc) return rc;
+    a.partial = p->partial.p;
+  }
+  launch_conv_igemm(a, st);
+  return 0;
+}
+
+static int image_encoder(odevio_plan* p, const float* img, int B, int S, float* fv, int ld_fv, hipStream_t st) {
+  const int P = B * (S - 1);
+  size_t nA = 0, nB = 0;
+  for (int i = 0; i < 9; ++i) {
+    const size_t n = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * kConvs[i].cout;
+    if (i == 0 || i == 2 || i == 4 || i == 6 || i == 8) nA = std::max(nA, n); else nB = std::max(nB, n);
+  }
+  int rc;
+  if ((rc = ensure(p->actA, nA))) return rc;
+  if ((rc = ensure(p->actB, nB))) return rc;
+  stage_mark(p, 0, st);
+  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, st))) return rc;
+  stage_mark(p, 1, st);
+  float* cur = p->actA.p;
+  for (int i = 1; i < 9; ++i) {
+    float* nxt = (cur == p->actA.p) ? p->actB.p : p->actA.p;
+    if ((rc = conv_block(p, i, cur, B, S, nxt, st))) return rc;
+    cur = nxt;
+  }
+  stage_mark(p, 2, st);
+  rc = run_gemm(p, cur, P, p->head_k, p->head_w, p->cfg.v_f_len, nullptr, p->head_b, nullptr, 0, fv, ld_fv, EPI_NONE, 0.f, st);
+  stage_mark(p, 3, st);
+  return rc;
+}
+
+static int imu_encoder(odevio_plan* p, const float* imu, int B, int T, float* fi, int ld_fi, hipStream_t st) {
+  const int pps = (T - 1) / 10;
+  const int P = B * pps;
+  int rc;
+  if ((rc = ensure(p->imu_act, (size_t)P * 2816))) return rc;
+  ImuArgs a{};
+  a.imu = imu; a.w1t = p->imu_w[0]; a.w2t = p->imu_w[1]; a.w3t = p->imu_w[2];
+  a.s1 = p->imu_s[0]; a.h1 = p->imu_h[0]; a.s2 = p->imu_s[1]; a.h2 = p->imu_h[1]; a.s3 = p->imu_s[2]; a.h3 = p->imu_h[2];
+  a.out = p->imu_act.p; a.B = B; a.T = T; a.pairs_per_seq = pps;
+  launch_imu_convs(a, st);
+  return run_gemm(p, p->imu_act.p, P, 2816, p->proj_w, p->cfg.i_f_len, nullptr, p->proj_b, nullptr, 0, fi, ld_fi,
+                  EPI_NONE, 0.f, st);
+}
+
+__global__ void concat_kernel(const float* fv, int nv, const float* fi, int ni, float* out, int P) {
+  const int F = nv + ni;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)P * F; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / F), c = (int)(i - (size_t)r * F);
+    out[i] = c < nv ? fv[(size_t)r * nv + c] : fi[(size_t)r * ni + (c - nv)];
+  }
+}
+
+// fcat [P][F] (already concatenated) -> fused [P][F]
+static int fuse_from_cat(odevio_plan* p, const float* fcat, int P, float* fused, hipStream_t st) {
+  const int F = p->F;
+  if (p->cfg.fuse_method == ODEVIO_FUSE_CAT) {
+    if (fused != fcat) HIPCHK(hipMemcpyAsync(fused, fcat, (size_t)P * F * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  return run_gemm(p, fcat, P, F, p->fuse_w, F, nullptr, p->fuse_b, fcat, F, fused, F, EPI_NONE, 0.f, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+static void fill_tableau(int solver, IntegTableau& t) {
+  memset(&t, 0, sizeof(t));
+  auto set_a = [&](int i, std::initializer_list<double> row) {
+    int j = 0;
+    for (double v : row) t.a[i][j++] = (float)v;
+  };
+  auto set_v = [&](float* dst, std::initializer_list<double> row) {
+    int j = 0;
+    for (double v : row) dst[j++] = (float)v;
+  };
+  switch (solver) {
+    case ODEVIO_DOPRI5:
+      t.stages = 7; t.fsal = 1; t.has_err = 1; t.order = 5;
+      set_a(1, {1 / 5.});
+      set_a(2, {3 / 40., 9 / 40.});
+      set_a(3, {44 / 45., -56 / 15., 32 / 9.});
+      set_a(4, {19372 / 6561., -25360 / 2187., 64448 / 6561., -212 / 729.});
+      set_a(5, {9017 / 3168., -355 / 33., 46732 / 5247., 49 / 176., -5103 / 18656.});
+      set_a(6, {35 / 384., 0., 500 / 1113., 125 / 192., -2187 / 6784., 11 / 84.});
+      set_v(t.b, {35 / 384., 0., 500 / 1113., 125 / 192., -2187 / 6784., 11 / 84., 0.});
+      set_v(t.e, {35 / 384. - 5179 / 57600., 0., 500 / 1113. - 7571 / 16695., 125 / 192. - 393 / 640.,
+                  -2187 / 6784. + 92097 / 339200., 11 / 84. - 187 / 2100., -1 / 40.});
+      break;
+    case ODEVIO_TSIT5:
+      t.stages = 7; t.fsal = 1; t.has_err = 1; t.order = 5;
+      set_a(1, {0.161});
+      set_a(2, {-0.008480655492356989, 0.335480655492357});
+      set_a(3, {2.8971530571054935, -6.359448489975075, 4.3622954328695815});
+      set_a(4, {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525});
+      set_a(5, {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383});
+      set_a(6, {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774});
+      set_v(t.b, {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774, 0.});
+      set_v(t.e, {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+                  0.5823571654525552, -0.45808210592918697, 1 / 66.});
+      break;
+    case ODEVIO_HEUN:
+      t.stages = 2; t.fsal = 0; t.has_err = 1; t.order = 2;
+      set_a(1, {1.0});
+      set_v(t.b, {0.5, 0.5});
+      set_v(t.e, {-0.5, 0.5});
+      break;
+    case ODEVIO_EULER:
+      t.stages = 1; t.fsal = 0; t.has_err = 0; t.order = 1;
+      set_v(t.b, {1.0});
+      break;
+    case ODEVIO_RK4:  // 3/8 rule (torchdiffeq rk4_alt_step_func)
+      t.stages = 4; t.fsal = 0; t.has_err = 0; t.order = 4;
+      set_a(1, {1 / 3.});
+      set_a(2, {-1 / 3., 1.0});
+      set_a(3, {1.0, -1.0, 1.0});
+      set_v(t.b, {1 / 8., 3 / 8., 3 / 8., 1 / 8.});
+      break;
+    default:  // ODEVIO_RK4_CLASSIC
+      t.stages = 4; t.fsal = 0; t.has_err = 0; t.order = 4;
+      set_a(1, {0.5});
+      set_a(2, {0., 0.5});
+      set_a(3, {0., 0., 1.0});
+      set_v(t.b, {1 / 6., 1 / 3., 1 / 3., 1 / 6.});
+      break;
+  }
+}
+
+static bool is_fixed_step(int solver) { return solver == ODEVIO_RK4 || solver == ODEVIO_RK4_CLASSIC; }
+
+// Fills everything that does not depend on the launch's rows and carves LDS for `rt` rows.
+static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int substeps, size_t* lds_bytes) {
+  const odevio_config& c = p->cfg;
+  memset(&a, 0, sizeof(a));
+  a.F = p->F; a.H = c.ode_hidden_dim; a.nlin = p->nlin; a.act = c.ode_activation;
+  for (int l = 0; l <= p->nlin; ++l) a.dims[l] = p->dims[l];
+  for (int l = 0; l < p->nlin; ++l) { a.w[l] = p->ode_w[l]; a.b[l] = p->ode_b[l]; a.w_lds_off[l] = -1; }
+  a.rnn_type = c.rnn_type; a.L = c.rnn_num_layers; a.rnn_vcols = p->rnn_vcols;
+  for (int l = 0; l < a.L; ++l) { a.rw[l] = p->rnn_w[l]; a.rb[l] = p->rnn_b[l]; }
+  fill_tableau(solver, a.tab);
+  a.nsub = is_fixed_step(solver) ? substeps : 0;
+  a.atol = c.atol; a.rtol = c.rtol; a.dt0 = c.dt0; a.max_steps = c.max_steps;
+  a.xbuf = p->xbuf; a.xstride = p->xstride; a.status = p->status;
+  // LDS carve (floats)
+  int maxdim = a.F;
+  for (int l = 0; l <= p->nlin; ++l) maxdim = std::max(maxdim, p->dims[l]);
+  int off = 0;
+  a.lds_xin = off; off += rt * maxdim;
+  a.lds_hst = off; off += rt * a.F;
+  a.lds_misc = off; off += 64 + rt * 32 * 2 + 128 * rt;
+  off = (off + 3) & ~3;
+  a.lds_w = off;
+  int budget = (160 * 1024 - 1024) / 4 - off;  // 1 KB left for the kernel's static LDS (__syncthreads_or scratch)
+  // keep the largest slices that fit resident; the rest stream from L2
+  std::vector<int> order(p->nlin);
+  for (int l = 0; l < p->nlin; ++l) order[l] = l;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    return (size_t)p->dims[x] * p->dims[x + 1] > (size_t)p->dims[y] * p->dims[y + 1];
+  });
+  int woff = 0;
+  for (int l : order) {
+    const int n = (p->dims[l + 1] / INTEG_MEMBERS) * p->dims[l];
+    if (n <= budget) { a.w_lds_off[l] = woff; woff += n; budget -= n; }
+  }
+  *lds_bytes = (size_t)(off + woff) * sizeof(float);
+  return 0;
+}
+
+static int launch_integ(odevio_plan* p, IntegArgs& a, int rt, size_t lds, hipStream_t st) {
+  if (p->n_cu < INTEG_GROUPS * INTEG_MEMBERS)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "persistent integrator needs %d CUs, device has %d", INTEG_GROUPS * INTEG_MEMBERS, p->n_cu);
+  HIPCHK(hipMemsetAsync(p->xbuf, 0, (size_t)INTEG_GROUPS * 2 * p->xstride * sizeof(unsigned long long), st));
+  const int e = launch_integrator(a, rt, lds, st);
+  if (e != 0) return fail(ODEVIO_ERR_HIP, "integrator launch failed: %s (lds %zu B)", hipGetErrorString((hipError_t)e), lds);
+  return 0;
+}
+
+static int run_sequence(odevio_plan* p, const float* fused, const float* ts, const float* hc, int B, int P,
+                        float* out_seq, float* hT, int32_t* stats, hipStream_t st) {
+  const int L = p->cfg.rnn_num_layers;
+  const int bpg_max = 8 / L;  // rows per group <= 8
+  const int chunk = INTEG_GROUPS * bpg_max;
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = std::min(chunk, B - b0);
+    const int BPG = (nb + INTEG_GROUPS - 1) / INTEG_GROUPS;
+    const int R = L * BPG;
+    const int rt = R <= 4 ? 4 : 8;
+    IntegArgs a;
+    size_t lds;
+    int rc = integ_common(p, a, rt, p->cfg.ode_solver, p->cfg.ode_substeps, &lds);
+    if (rc) return rc;
+    a.mode = p->cfg.model_type == ODEVIO_MODEL_RNN ? MODE_RNN_ONLY : MODE_ODE_RNN;
+    a.B = B; a.P = P; a.b_begin = b0; a.b_end = b0 + nb;
+    a.BPG = BPG; a.G = (nb + BPG - 1) / BPG; a.rows_per_group = R;
+    a.fused = fused; a.ts = ts; a.ts_relative = hc ? 0 : 1; a.hc = hc; a.out_seq = out_seq; a.hT = hT; a.stats = stats;
+    if ((rc = launch_integ(p, a, rt, lds, st))) return rc;
+  }
+  return 0;
+}
+
+static int run_rows(odevio_plan* p, int mode, const float* y, const float* t0, const float* t1, int rows, int solver,
+                    int substeps, float* y_out, int32_t* stats, hipStream_t st) {
+  if (p->cfg.model_type != ODEVIO_MODEL_ODE_RNN) return fail(ODEVIO_ERR_UNSUPPORTED, "plan has no ODEFunc");
+  const int chunk = INTEG_GROUPS * 8;
+  for (int r0 = 0; r0 < rows; r0 += chunk) {
+    const int nr = std::min(chunk, rows - r0);
+    const int BPG = (nr + INTEG_GROUPS - 1) / INTEG_GROUPS;
+    const int rt = BPG <= 4 ? 4 : 8;
+    IntegArgs a;
+    size_t lds;
+    int rc = integ_common(p, a, rt, solver, substeps, &lds);
+    if (rc) return rc;
+    a.mode = mode;
+    a.B = rows; a.P = 1; a.b_begin = r0; a.b_end = r0 + nr;
+    a.BPG = BPG; a.G = (nr + BPG - 1) / BPG; a.rows_per_group = BPG;
+    a.y0 = y; a.t0 = t0; a.t1 = t1; a.y_out = y_out; a.stats = stats;
+    if ((rc = launch_integ(p, a, rt, lds, st))) return rc;
+  }
+  return 0;
+}
+
+static int regress(odevio_plan* p, const float* seq, int M, float* poses, hipStream_t st) {
+  int rc;
+  if ((rc = ensure(p->reg_hid, (size_t)M * 128))) return rc;
+  if ((rc = run_gemm(p, seq, M, p->F, p->reg_w0, 128, nullptr, p->reg_b0, nullptr, 0, p->reg_hid.p, 128, EPI_LEAKY, 0.1f, st)))
+    return rc;
+  return run_gemm(p, p->reg_hid.p, M, 128, p->reg_w2, 6, nullptr, p->reg_b2, nullptr, 0, poses, 6, EPI_NONE, 0.f, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+#define ARGCHK(cond, msg) \
+  if (!(cond)) return fail(ODEVIO_ERR_BAD_ARG, msg)
+
+extern "C" int odevio_reserve(odevio_plan* p, int32_t B, int32_t S, void* stream) {
+  ARGCHK(p && B > 0 && S > 1, "odevio_reserve: bad argument");
+  const int P = B * (S - 1);
+  size_t nA = 0, nB = 0;
+  for (int i = 0; i < 9; ++i) {
+    const size_t n = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * kConvs[i].cout;
+    if (i % 2 == 0) nA = std::max(nA, n); else nB = std::max(nB, n);
+  }
+  int rc;
+  if ((rc = ensure(p->actA, nA)) || (rc = ensure(p->actB, nB)) || (rc = ensure(p->imu_act, (size_t)P * 2816)) ||
+      (rc = ensure(p->fcat, (size_t)P * p->F)) || (rc = ensure(p->fused, (size_t)P * p->F)) ||
+      (rc = ensure(p->out_seq, (size_t)P * p->F)) || (rc = ensure(p->reg_hid, (size_t)P * 128)) ||
+      (rc = ensure(p->partial, (size_t)64 * P * std::max(p->cfg.v_f_len, 128))))
+    return rc;
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int odevio_profile_enable(odevio_plan* p, int32_t on) {
+  ARGCHK(p, "odevio_profile_enable: null plan");
+  if (on && !p->ev[0])
+    for (int i = 0; i <= ODEVIO_N_STAGES; ++i) HIPCHK(hipEventCreate(&p->ev[i]));
+  p->prof = on != 0;
+  return 0;
+}
+
+extern "C" int odevio_profile_read(odevio_plan* p, float* ms_out) {
+  ARGCHK(p && ms_out && p->prof, "odevio_profile_read: profiling is not enabled");
+  HIPCHK(hipEventSynchronize(p->ev[ODEVIO_N_STAGES]));
+  for (int i = 0; i < ODEVIO_N_STAGES; ++i) HIPCHK(hipEventElapsedTime(&ms_out[i], p->ev[i], p->ev[i + 1]));
+  return 0;
+}
+
+extern "C" int odevio_check(odevio_plan* p, void* stream) {
+  ARGCHK(p, "odevio_check: null plan");
+  hipStream_t st = (hipStream_t)stream;
+  int h = 0;
+  HIPCHK(hipMemcpyAsync(&h, p->status, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (h != 0) {
+    HIPCHK(hipMemsetAsync(p->status, 0, sizeof(int), st));
+    HIPCHK(hipStreamSynchronize(st));
+    return fail(h, h == ODEVIO_ERR_TIMEOUT ? "integrator: a bounded in-kernel wait timed out"
+                                           : "integrator: adaptive solver exceeded max_steps");
+  }
+  return 0;
+}
+
+extern "C" int odevio_image_encoder_fwd(odevio_plan* p, const float* img, int32_t B, int32_t S, float* fv,
+                                        int32_t ld_fv, void* stream) {
+  ARGCHK(p && img && fv && B > 0 && S > 1 && ld_fv >= p->cfg.v_f_len, "odevio_image_encoder_fwd: bad argument");
+  return image_encoder(p, img, B, S, fv, ld_fv, (hipStream_t)stream);
+}
+
+extern "C" int odevio_conv_block_fwd(odevio_plan* p, int32_t layer, const float* in, int32_t B, int32_t S, float* out,
+                                     void* stream) {
+  ARGCHK(p && in && out && layer >= 0 && layer < 9 && B > 0 && S > 1, "odevio_conv_block_fwd: bad argument");
+  return conv_block(p, layer, in, B, S, out, (hipStream_t)stream);
+}
+
+extern "C" int odevio_imu_encoder_fwd(odevio_plan* p, const float* imu, int32_t B, int32_t T, float* fi,
+                                      int32_t ld_fi, void* stream) {
+  ARGCHK(p && imu && fi && B > 0 && T >= 11 && ld_fi >= p->cfg.i_f_len, "odevio_imu_encoder_fwd: bad argument");
+  return imu_encoder(p, imu, B, T, fi, ld_fi, (hipStream_t)stream);
+}
+
+extern "C" int odevio_fuse_fwd(odevio_plan* p, const float* fv, const float* fi, int32_t P, float* fused, void* stream) {
+  ARGCHK(p && fv && fi && fused && P > 0, "odevio_fuse_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  float* cat = fused;
+  if (p->cfg.fuse_method != ODEVIO_FUSE_CAT) {
+    if ((rc = ensure(p->fcat, (size_t)P * p->F))) return rc;
+    cat = p->fcat.p;
+  }
+  hipLaunchKernelGGL(concat_kernel, dim3(std::min(1024, (P * p->F + 255) / 256)), dim3(256), 0, st, fv, p->cfg.v_f_len, fi,
+                     p->cfg.i_f_len, cat, P);
+  return fuse_from_cat(p, cat, P, fused, st);
+}
+
+extern "C" int odevio_ode_func(odevio_plan* p, const float* y, int32_t rows, float* out, void* stream) {
+  ARGCHK(p && y && out && rows > 0, "odevio_ode_func: bad argument");
+  return run_rows(p, MODE_FEVAL, y, nullptr, nullptr, rows, p->cfg.ode_solver, 1, out, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int odevio_ode_steps(odevio_plan* p, const float* y, const float* t0, const float* t1, int32_t rows,
+                                int32_t solver, int32_t substeps, float* y_out, int32_t* stats, void* stream) {
+  ARGCHK(p && y && t0 && t1 && y_out && rows > 0, "odevio_ode_steps: bad argument");
+  if (solver < 0) solver = p->cfg.ode_solver;
+  if (solver > ODEVIO_RK4_CLASSIC) return fail(ODEVIO_ERR_BAD_ARG, "Solver not supported");
+  if (substeps <= 0) substeps = p->cfg.ode_substeps;
+  return run_rows(p, MODE_ODE_STEPS, y, t0, t1, rows, solver, substeps, y_out, stats, (hipStream_t)stream);
+}
+
+extern "C" int odevio_ode_rnn_fwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B,
+                                  int32_t P, float* poses, float* h_T, int32_t* stats, void* stream) {
+  ARGCHK(p && fused && ts && poses && h_T && B > 0 && P > 0, "odevio_ode_rnn_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure(p->out_seq, (size_t)B * P * p->F))) return rc;
+  stage_mark(p, 4, st);
+  if ((rc = run_sequence(p, fused, ts, hc_in, B, P, p->out_seq.p, h_T, stats, st))) return rc;
+  stage_mark(p, 5, st);
+  rc = regress(p, p->out_seq.p, B * P, poses, st);
+  stage_mark(p, 6, st);
+  return rc;
+}
+
+extern "C" int odevio_forward(odevio_plan* p, const float* img, const float* imu, int32_t T, const float* ts,
+                              const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats,
+                              void* stream) {
+  ARGCHK(p && img && imu && ts && poses && h_T && B > 0 && S > 1, "odevio_forward: bad argument");
+  if ((T - 1) / 10 != S - 1) return fail(ODEVIO_ERR_BAD_ARG, "imu length %d does not give %d frame pairs", T, S - 1);
+  hipStream_t st = (hipStream_t)stream;
+  const int P = B * (S - 1), F = p->F;
+  int rc;
+  if ((rc = ensure(p->fcat, (size_t)P * F)) || (rc = ensure(p->fused, (size_t)P * F))) return rc;
+  // encoders write straight into the concatenated feature rows (torch.cat of FusionModule.py:19 is free)
+  if ((rc = image_encoder(p, img, B, S, p->fcat.p, F, st))) return rc;
+  if ((rc = imu_encoder(p, imu, B, T, p->fcat.p + p->cfg.v_f_len, F, st))) return rc;
+  const float* fused = p->fcat.p;
+  if (p->cfg.fuse_method != ODEVIO_FUSE_CAT) {
+    if ((rc = fuse_from_cat(p, p->fcat.p, P, p->fused.p, st))) return rc;
+    fused = p->fused.p;
+  }
+  return odevio_ode_rnn_fwd(p, fused, ts, hc, B, S - 1, poses, h_T, stats, stream);
+}

@@ -1,0 +1,336 @@
+// Implicit-GEMM convolution / linear layer on the fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// Replaces the cuDNN/ATen Conv2d + BatchNorm2d(eval) + LeakyReLU(0.1) blocks of the reference's
+// ImageEncoder (src/models/Encoder.py:8-22,116-122) for conv2..conv6, and every nn.Linear of the
+// path that is not inside the integrator (visual_head, Inertial proj, fusion, regressor).
+//
+// Tiling: 128(M) x 128(N) x 32(K) per 256-thread workgroup; 4 waves, each a 64x64 sub-tile =
+// 2x2 MFMA 32x32 accumulators (64 VGPRs).  K runs over (kh, kw, cin-chunk-of-32): with NHWC
+// activations and [Cout][kh][kw][Cin] weights both operands are 128-byte contiguous runs, so the
+// im2col matrix is never materialised.  Operands are register-staged (global_load_dwordx4 issued
+// one K-tile ahead, ds_write_b128 after the MFMAs) into double-buffered LDS with a 36-float row
+// stride, which makes the ds_read_b128 fragment reads conflict-free.  The MFMA's two k-lanes are
+// mapped to k = h*16 + kk (h = lane>>5): any bijection works as long as A and B agree, and this
+// one lets each lane fetch its 16 k-values of a row with four ds_read_b128.
+// The f32 MFMA is an exact k-ordered fmaf chain, so results differ from the CPU oracle only by
+// summation order.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDS_LD 36  // padded row stride (floats): 144 B = 9 x 16 B, co-prime slot walk
+
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- loader role: rows lrow + 32q, one float4 at column lc4*4
+  const int lrow = tid >> 3;
+  const int lc4 = (tid & 7) * 4;
+  const float* a_img[4];
+  int a_hi0[4], a_wi0[4];
+  const float* b_row[4];
+  const int HoWo = a.Ho * a.Wo;
+  const int taps = a.KH * a.KW;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + lrow + 32 * q;
+    if (m < a.M) {
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      a_img[q] = a.in + (size_t)img * a.Hi * a.Wi * a.Cin;
+      a_hi0[q] = ho * a.stride - a.pad;
+      a_wi0[q] = wo * a.stride - a.pad;
+    } else {
+      a_img[q] = a.in;
+      a_hi0[q] = -(1 << 28);
+      a_wi0[q] = -(1 << 28);
+    }
+    const int n = n0 + lrow + 32 * q;
+    b_row[q] = (n < a.Cout) ? a.w + (size_t)n * taps * a.Cin : nullptr;
+  }
+
+  const int cpt = a.Cin / BK;  // cin chunks per tap
+  const int nk = taps * cpt;
+  int kt_begin = 0, kt_end = nk;
+  if (a.splitk > 1) {
+    kt_begin = blockIdx.z * a.ktiles_per_split;
+    kt_end = min(nk, kt_begin + a.ktiles_per_split);
+  }
+
+  f32x4 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+    const int tap = kt / cpt;
+    const int cc = (kt - tap * cpt) * BK + lc4;
+    const int kh = tap / a.KW;
+    const int kw = tap - kh * a.KW;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int hi = a_hi0[q] + kh, wi = a_wi0[q] + kw;
+      const bool ok = (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a_img[q] + ((size_t)hi * a.Wi + wi) * a.Cin + cc);
+      ra[q] = v;
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+      if (b_row[q]) u = *reinterpret_cast<const f32x4*>(b_row[q] + (size_t)tap * a.Cin + cc);
+      rb[q] = u;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * q) * LDS_LD + lc4]) = ra[q];
+      *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * q) * LDS_LD + lc4]) = rb[q];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fi = lane & 31, fh = lane >> 5;
+  const int a_off = (wm * 64 + fi) * LDS_LD + fh * 16;
+  const int b_off = (wn * 64 + fi) * LDS_LD + fh * 16;
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = (kt + 1 < kt_end);
+    if (more) load_tile(kt + 1);
+    const float* Ab = &As[buf][a_off];
+    const float* Bb = &Bs[buf][b_off];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + k4 * 4);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + 32 * LDS_LD + k4 * 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bb + k4 * 4);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bb + 32 * LDS_LD + k4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = n0 + wn * 64 + nt * 32 + fi;
+      if (n >= a.Cout) continue;
+      float sc = 1.f, sh = 0.f;
+      if (a.splitk <= 1) {
+        if (a.scale) sc = a.scale[n];
+        if (a.shift) sh = a.shift[n];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m >= a.M) continue;
+        float v = acc[mt][nt][r];
+        if (a.splitk > 1) {
+          a.partial[((size_t)blockIdx.z * a.M + m) * a.Cout + n] = v;
+        } else {
+          v = apply_epi(v * sc + sh, a.act, a.slope);
+          if (a.mul) v *= a.mul[(size_t)m * a.ld_mul + n];
+          a.out[(size_t)m * a.ld_out + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// Deterministic split-K combine: sums the slabs in slab order, then the same epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
+  const size_t total = (size_t)a.M * a.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / a.Cout);
+    const int n = (int)(idx - (size_t)m * a.Cout);
+    float v = 0.f;
+    for (int z = 0; z < a.splitk; ++z) v += a.partial[(size_t)z * total + idx];
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+    v = apply_epi(v * sc + sh, a.act, a.slope);
+    if (a.mul) v *= a.mul[(size_t)m * a.ld_mul + n];
+    a.out[(size_t)m * a.ld_out + n] = v;
+  }
+}
+
+void launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
+  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.splitk > 1 ? a.splitk : 1);
+  hipLaunchKernelGGL(conv_igemm_kernel, grid, dim3(256), 0, st, a);
+  if (a.splitk > 1) {
+    const size_t total = (size_t)a.M * a.Cout;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv1: Conv2d(6 -> 64, k7, s2, p3) + BN + LeakyReLU(0.1), reading frame pairs IN PLACE from
+// img [B][S][3][H][W] (the reference's torch.cat of consecutive frames, Encoder.py:101, is never
+// materialised: frames i and i+1 are adjacent in memory, so the pair's six planes are one run).
+//
+// Persistent workgroups (one per CU) keep the whole 294 x 64 weight matrix resident in LDS and walk
+// 8 x 32-pixel output tiles; the input patch (6 x 21 x 69 floats) is double-buffered in LDS and
+// register-prefetched under the previous tile's MFMAs.  K = 294 is split between the MFMA's two
+// k-lanes as frame i (k = 0..146) / frame i+1 (k = 147..293), so at k-step s both halves read the
+// same (channel, kh, kw) offset from their own frame: every LDS address is lane_base + immediate.
+// ------------------------------------------------------------------------------------------------
+#define C1_TH 8
+#define C1_TW 32
+#define C1_PH (2 * C1_TH + 5)       // 21
+#define C1_PW (2 * C1_TW + 5)       // 69
+#define C1_PATCH (6 * C1_PH * C1_PW)  // 8694 floats
+#define C1_PATCH_PER_THREAD ((C1_PATCH + 255) / 256)  // 34
+#define C1_KHALF 147
+
+__global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                       // [294][64]
+  float* Ps0 = smem + 294 * 64;           // patch buffers
+  float* Ps1 = Ps0 + C1_PATCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int fi = lane & 31, fh = lane >> 5;
+
+  for (int i = tid; i < 294 * 64; i += 256) Ws[i] = a.wt[i];
+
+  const int tiles_per_pair = a.tiles_y * a.tiles_x;
+  const size_t plane = (size_t)a.H * a.W;
+  float stage[C1_PATCH_PER_THREAD];
+
+  auto load_patch = [&](int tile) {
+    const int pair = tile / tiles_per_pair;
+    const int t = tile - pair * tiles_per_pair;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int b = pair / (a.S - 1), fr = pair - b * (a.S - 1);
+    const float* base = a.img + ((size_t)b * a.S + fr) * 3 * plane;
+    const int gy0 = 2 * ty * C1_TH - 3, gx0 = 2 * tx * C1_TW - 3;
+#pragma unroll
+    for (int j = 0; j < C1_PATCH_PER_THREAD; ++j) {
+      const int idx = tid + 256 * j;
+      float v = 0.f;
+      if (idx < C1_PATCH) {
+        const int c = idx / (C1_PH * C1_PW);
+        const int r = idx - c * (C1_PH * C1_PW);
+        const int y = r / C1_PW, x = r - y * C1_PW;
+        const int gy = gy0 + y, gx = gx0 + x;
+        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v = base[c * plane + (size_t)gy * a.W + gx];
+      }
+      stage[j] = v;
+    }
+  };
+  auto store_patch = [&](float* Ps) {
+#pragma unroll
+    for (int j = 0; j < C1_PATCH_PER_THREAD; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < C1_PATCH) Ps[idx] = stage[j];
+    }
+  };
+
+  // lane bases: frame half fh owns channels 3*fh..3*fh+2; wave owns output rows 2*wave, 2*wave+1
+  const int a_base = (fh * 3) * C1_PH * C1_PW + (4 * wave) * C1_PW + 2 * fi;
+  const int b_base = (fh * C1_KHALF) * 64 + fi;
+
+  int tile = blockIdx.x;
+  int buf = 0;
+  if (tile < a.n_tiles) {
+    load_patch(tile);
+    store_patch(Ps0);
+  }
+  __syncthreads();
+  for (; tile < a.n_tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < a.n_tiles) load_patch(next);
+    const float* Ps = buf ? Ps1 : Ps0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* Ap = Ps + a_base;
+    const float* Bp = Ws + b_base;
+#pragma unroll
+    for (int s = 0; s < C1_KHALF; ++s) {
+      const int c3 = s / 49, kh = (s % 49) / 7, kw = s % 7;
+      const int off = (c3 * C1_PH + kh) * C1_PW + kw;
+      const float a0 = Ap[off];
+      const float a1 = Ap[off + 2 * C1_PW];
+      const float b0 = Bp[s * 64];
+      const float b1 = Bp[s * 64 + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // epilogue: rows of the MFMA tile are the 32 pixels of one output row segment
+    {
+      const int pair = tile / tiles_per_pair;
+      const int t = tile - pair * tiles_per_pair;
+      const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int oy = ty * C1_TH + 2 * wave + mt;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int n = nt * 32 + fi;
+          const float sc = a.scale[n], sh = a.shift[n];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ox = tx * C1_TW + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (oy < a.Ho && ox < a.Wo) {
+              float v = acc[mt][nt][r] * sc + sh;
+              v = v > 0.f ? v : v * a.slope;
+              a.out[(((size_t)pair * a.Ho + oy) * a.Wo + ox) * 64 + n] = v;
+            }
+          }
+        }
+      }
+    }
+    if (next < a.n_tiles) store_patch(buf ? Ps0 : Ps1);
+    buf ^= 1;
+    __syncthreads();
+  }
+}
+
+void launch_conv1(const Conv1Args& a, int n_cu, hipStream_t st) {
+  const size_t lds = (size_t)(294 * 64 + 2 * C1_PATCH) * sizeof(float);  // 144,816 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  int grid = n_cu < a.n_tiles ? n_cu : a.n_tiles;
+  hipLaunchKernelGGL(conv1_kernel, dim3(grid), dim3(256), lds, st, a);
+}

@@ -1,0 +1,65 @@
+// Argument block of the persistent ODE-RNN integrator kernel (integrator.hip).
+#pragma once
+#include <stdint.h>
+
+#define INTEG_MAX_LIN 6    // Linears in ODEFunc (ode_fn_num_layers + 1)
+#define INTEG_MAX_L 4      // RNN layers
+#define INTEG_MEMBERS 32   // workgroups (CUs) per row group = one XCD under round-robin dispatch
+#define INTEG_GROUPS 8
+#define INTEG_KMAX 1024    // widest vector exchanged between layers
+
+enum IntegMode { MODE_ODE_RNN = 0, MODE_RNN_ONLY = 1, MODE_ODE_STEPS = 2, MODE_FEVAL = 3 };
+
+// Butcher tableau handed to the kernel in the argument block (scalar loads).
+struct IntegTableau {
+  int stages;
+  int fsal;       // last stage is f(y1): reuse it as the next step's first stage
+  int has_err;    // embedded error estimate -> adaptive I-controller
+  int order;      // exponent -1/order of the controller
+  float a[7][7];
+  float b[7];
+  float e[7];     // b - b_hat
+};
+
+struct IntegArgs {
+  // ---- vector field  f(y) = tanh(W_n act(... act(W_1 y + b_1)) + b_n)
+  int F, H, nlin, act;
+  int dims[INTEG_MAX_LIN + 1];            // F, H, ..., H, F
+  const float* w[INTEG_MAX_LIN];          // per-member slices, layout [member][j][col][ks][4]
+  const float* b[INTEG_MAX_LIN];          // full bias vectors
+  int w_lds_off[INTEG_MAX_LIN];           // float offset of the LDS-resident copy, or -1 = stream from L2
+  // ---- RNN stack
+  int rnn_type, L, rnn_vcols;             // virtual columns per hidden unit: 1 (tanh RNN) or 4 (GRU: r, z, n_i, n_h)
+  const float* rw[INTEG_MAX_L];           // [member][j][col][ks][4], K = 2F ([input | hidden])
+  const float* rb[INTEG_MAX_L];           // [vcols][F] folded biases
+  // ---- solver
+  IntegTableau tab;
+  int nsub;
+  float atol, rtol, dt0;
+  int max_steps;
+  // ---- problem
+  int mode;
+  int B, P;                               // batch (tensor stride), intervals (timestamps per row = P + 1)
+  int b_begin, b_end;                     // batch elements (sequence modes) or rows (row modes) of THIS launch
+  int G, BPG;                             // active groups, batch elements (or rows) per group
+  int rows_per_group;                     // L*BPG (sequence modes) or BPG (row modes)
+  const float* fused;                     // [B][P][F]
+  const float* ts;                        // [B][P+1]
+  int ts_relative;                        // 1: subtract ts[:,0] (hc == NULL), reference PoseODERNN.py:100
+  const float* hc;                        // [L][B][F] or null
+  float* out_seq;                         // [B][P][F] top-layer RNN outputs
+  float* hT;                              // [L][B][F]
+  const float* y0;                        // row modes: [rows][F]
+  const float* t0;                        // [rows]
+  const float* t1;                        // [rows]
+  float* y_out;                           // [rows][F]
+  int* stats;                             // [rows][2] or null
+  // ---- infrastructure
+  unsigned long long* xbuf;               // [G][2][xstride] 8-byte {tag, value} granules
+  int xstride;
+  int* status;                            // device status word (0 = ok)
+  // ---- LDS carve (float offsets)
+  int lds_xin, lds_hst, lds_misc, lds_w;
+};
+
+int launch_integrator(const IntegArgs& a, int rt, size_t lds_bytes, void* stream);

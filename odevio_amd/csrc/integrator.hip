@@ -1,0 +1,589 @@
+// Persistent ODE-RNN integrator for gfx950: the whole `for i in range(seq_len)` loop of the
+// reference's PoseODERNN.forward (src/models/PoseODERNN.py:97-123) - per interval an ODE solve of
+// every RNN layer's hidden state (torchode in the reference, :70-75) followed by one nn.RNN/nn.GRU
+// step (:114) - in ONE kernel launch.
+//
+// Why persistent: one RK4 step of the [R = L*B, 768] state is 16 dependent skinny GEMMs; at R = 32
+// the arithmetic is microseconds of work and a launch boundary costs ~1.5 us each, so the loop is
+// latency-bound by construction.
+//
+// Decomposition (MI355X-first):
+//  * rows (batch elements x RNN layers) are independent in the ODE solve, so they are dealt to 8 ROW
+//    GROUPS; a group is 32 workgroups = one XCD under the observed round-robin dispatch
+//    (blockIdx & 7; speed only - correctness never depends on placement, see hand-off below);
+//  * inside a group the MLP is COLUMN-sharded: member c owns N/32 output columns of every layer
+//    and keeps its slice of the weights resident in LDS for the whole launch (one slice that does
+//    not fit streams from L2), so the 5.25 MB of ODEFunc parameters are read from HBM once per
+//    launch instead of once per stage;
+//  * between layers the members all-gather the [rows, N] activations through global memory with
+//    8-byte {tag, value} granules: written with relaxed agent-scope atomic stores (write-through,
+//    sc1) and polled with relaxed agent-scope atomic loads - the data is its own flag, so there is
+//    no fence, no separate flag and no dependence on XCD placement.  Two buffers alternate by
+//    exchange parity: a member can only write exchange e+2 after it has read all of e+1, which
+//    needs every member to have finished reading e, so a buffer is never overwritten while in use.
+//    Every poll is bounded (2 s wall clock) and gives up with ODEVIO_ERR_TIMEOUT in the status word.
+//  * per-row solver state (t, dt, accept, ...) is computed redundantly by every member from the
+//    same gathered numbers in the same order, so all members take identical control flow.
+//
+// Thread map (256 threads): ks = tid & 15 is a K-slice during a layer product and the ROW a thread
+// owns afterwards; slot = tid >> 4 is a column slot.  State element (row, local col) lives on the
+// thread (ks = row, slot = col % 16) in register col / 16.
+#include "common.h"
+#include "integrator.h"
+
+typedef unsigned long long u64;
+#define RLX __ATOMIC_RELAXED
+#define AGENT __HIP_MEMORY_SCOPE_AGENT
+#define ST_TIMEOUT (-6)
+#define ST_MAX_STEPS (-7)
+#define SPIN_TIMEOUT_TICKS 200000000ull  // 2 s of the 100 MHz s_memrealtime clock
+
+struct Ctx {
+  int tid, ks, slot, cu;
+  unsigned epoch;
+  u64* xb[2];
+  int* status;
+  bool failed;
+};
+
+__device__ __forceinline__ void put(u64* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), RLX, AGENT);
+}
+
+// Collect n granules of the current exchange into LDS dst[0..n).  Workgroup-uniform result.
+template <int MAXG>
+__device__ __forceinline__ void gather(Ctx& c, int n, float* dst) {
+  __syncthreads();  // every wave is done reading dst's previous contents
+  bool fail = false;
+  if (!c.failed) {
+    const u64* buf = c.xb[c.epoch & 1];
+    u64 g[MAXG];
+    unsigned pend = 0;
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j)
+      if (c.tid + 256 * j < n) pend |= 1u << j;
+    unsigned spins = 0;
+    u64 t_start = 0;
+    while (pend) {
+#pragma unroll
+      for (int j = 0; j < MAXG; ++j)
+        if ((pend >> j) & 1u) g[j] = __hip_atomic_load(buf + c.tid + 256 * j, RLX, AGENT);
+#pragma unroll
+      for (int j = 0; j < MAXG; ++j)
+        if (((pend >> j) & 1u) && (unsigned)(g[j] >> 32) == c.epoch) {
+          dst[c.tid + 256 * j] = __uint_as_float((unsigned)g[j]);
+          pend &= ~(1u << j);
+        }
+      if (pend) {
+        if ((++spins & 127u) == 0) {
+          const u64 now = __builtin_amdgcn_s_memrealtime();
+          if (t_start == 0) t_start = now;
+          if (now - t_start > SPIN_TIMEOUT_TICKS || __hip_atomic_load(c.status, RLX, AGENT) != 0) {
+            atomicCAS(c.status, 0, ST_TIMEOUT);
+            fail = true;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  if (__syncthreads_or(fail ? 1 : 0)) c.failed = true;
+}
+
+__device__ __forceinline__ float dot4(const f32x4 w, const f32x4 x, float acc) {
+  acc = fmaf(w[0], x[0], acc);
+  acc = fmaf(w[1], x[1], acc);
+  acc = fmaf(w[2], x[2], acc);
+  acc = fmaf(w[3], x[3], acc);
+  return acc;
+}
+
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// One layer product for this member: acc[c][r] = sum_k W[col_c][k] * x[r][k], c = 0,1 (local columns
+// col0 = pass*32 + slot and col0 + 16), r < RT.  Inputs k < K1 come from xa, the rest from xb.
+// On return every lane of a 16-lane group holds the full sums.
+template <int RT, bool WLDS>
+__device__ __forceinline__ void layer(const float* __restrict__ wbase, int NC, int K1, const float* xa, int lda,
+                                      int K2, const float* xb, int ldb, int nr, int col0, int ks,
+                                      float (&acc)[2][RT]) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[c][r] = 0.f;
+  const int c0 = col0 < NC ? col0 : NC - 1;  // clamp: out-of-range columns compute garbage that is discarded
+  const int c1 = col0 + 16 < NC ? col0 + 16 : c0;
+  const int nj = (K1 + K2) >> 6;
+  const int nj1 = K1 >> 6;
+#pragma unroll 2
+  for (int j = 0; j < nj; ++j) {
+    const float* xs;
+    int ld;
+    if (j < nj1) {
+      xs = xa + j * 64 + 4 * ks;
+      ld = lda;
+    } else {
+      xs = xb + (j - nj1) * 64 + 4 * ks;
+      ld = ldb;
+    }
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wbase + (((size_t)j * NC + c0) * 16 + ks) * 4);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wbase + (((size_t)j * NC + c1) * 16 + ks) * 4);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const int rr = r < nr ? r : nr - 1;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xs + rr * ld);
+      acc[0][r] = dot4(w0, x, acc[0][r]);
+      acc[1][r] = dot4(w1, x, acc[1][r]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[c][r] = group16_sum(acc[c][r]);
+}
+
+template <int RT>
+__device__ __forceinline__ float pick(const float (&v)[RT], int ks) {
+  float out = v[0];
+#pragma unroll
+  for (int r = 1; r < RT; ++r) out = (ks == r) ? v[r] : out;
+  return out;
+}
+
+__device__ __forceinline__ float hidden_act(float v, int act) {
+  switch (act) {
+    case 0: return tanhf(v);
+    case 1: return fmaxf(v, 0.f);
+    case 2: return v > 0.f ? v : 0.01f * v;
+    default: return v > 20.f ? v : log1pf(expf(v));  // nn.Softplus(beta=1, threshold=20)
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+template <int RT>
+__global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MAXG = RT * (INTEG_KMAX / 256);
+  Ctx c;
+  c.tid = threadIdx.x;
+  c.ks = c.tid & 15;
+  c.slot = c.tid >> 4;
+  const int g = blockIdx.x & (INTEG_GROUPS - 1);
+  c.cu = blockIdx.x >> 3;
+  if (g >= a.G) return;
+  c.epoch = 0;
+  c.xb[0] = a.xbuf + (size_t)(2 * g) * a.xstride;
+  c.xb[1] = a.xbuf + (size_t)(2 * g + 1) * a.xstride;
+  c.status = a.status;
+  c.failed = false;
+  const int tid = c.tid, ks = c.ks, slot = c.slot, cu = c.cu;
+
+  float* xin = smem + a.lds_xin;
+  float* hst = smem + a.lds_hst;
+  float* misc = smem + a.lds_misc;
+  float* red = misc;                  // [4][16]
+  float* nrm = misc + 64;             // [RT][32]
+  float* mv = nrm + RT * 32;          // [RT][32]
+  float* pre = mv + RT * 32;          // [4*32][RT]
+  float* wl = smem + a.lds_w;
+
+  // ---- resident weight slices -> LDS (read from HBM once per launch)
+  for (int l = 0; l < a.nlin; ++l) {
+    if (a.w_lds_off[l] < 0) continue;
+    const int n = (a.dims[l + 1] / INTEG_MEMBERS) * a.dims[l];
+    const float* src = a.w[l] + (size_t)cu * n;
+    float* dstw = wl + a.w_lds_off[l];
+    for (int i = tid * 4; i < n; i += 1024)
+      *reinterpret_cast<f32x4*>(dstw + i) = *reinterpret_cast<const f32x4*>(src + i);
+  }
+  __syncthreads();
+
+  const bool seq_mode = (a.mode == MODE_ODE_RNN || a.mode == MODE_RNN_ONLY);
+  const int F = a.F;
+  const int NCF = F / INTEG_MEMBERS;
+  const int R = a.rows_per_group;
+  const int BPG = a.BPG;
+  // this thread's row
+  const bool has_row = ks < R;
+  int row_l = 0, row_b = 0, grow = 0;  // layer, batch index, global row id
+  bool row_valid = false;
+  if (has_row) {
+    if (seq_mode) {
+      row_l = ks / BPG;
+      row_b = a.b_begin + g * BPG + (ks - row_l * BPG);
+      row_valid = row_b < a.b_end;
+      grow = row_l * a.B + row_b;
+    } else {
+      grow = a.b_begin + g * BPG + ks;
+      row_valid = grow < a.b_end;
+    }
+  }
+  // this thread's columns of an F-wide vector
+  int colg[2];
+  bool colv[2];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int cl = ci * 16 + slot;
+    colv[ci] = cl < NCF;
+    colg[ci] = cu * NCF + (colv[ci] ? cl : 0);
+  }
+
+  float y[2] = {0.f, 0.f};
+  if (row_valid) {
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      if (!colv[ci]) continue;
+      if (seq_mode) y[ci] = a.hc ? a.hc[(size_t)grow * F + colg[ci]] : 0.f;
+      else y[ci] = a.y0[(size_t)grow * F + colg[ci]];
+    }
+  }
+
+  // vector field: stage values sv (this thread's elements) -> kout
+  auto feval = [&](const float (&sv)[2], float (&kout)[2]) {
+    ++c.epoch;
+    if (has_row) {
+      u64* buf = c.xb[c.epoch & 1];
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci)
+        if (colv[ci]) put(buf + ks * F + colg[ci], sv[ci], c.epoch);
+    }
+    gather<MAXG>(c, R * F, xin);
+    for (int l = 0; l < a.nlin; ++l) {
+      const int K = a.dims[l], N = a.dims[l + 1];
+      const int NC = N / INTEG_MEMBERS;
+      float acc[2][RT];
+      if (a.w_lds_off[l] >= 0)
+        layer<RT, true>(wl + a.w_lds_off[l], NC, K, xin, K, 0, xin, K, R, slot, ks, acc);
+      else
+        layer<RT, false>(a.w[l] + (size_t)cu * NC * K, NC, K, xin, K, 0, xin, K, R, slot, ks, acc);
+      float v[2];
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci) {
+        const int cl = ci * 16 + slot;
+        const int cg = cu * NC + (cl < NC ? cl : 0);
+        v[ci] = pick<RT>(acc[ci], ks) + a.b[l][cg];
+      }
+      if (l + 1 < a.nlin) {
+        ++c.epoch;
+        if (has_row) {
+          u64* buf = c.xb[c.epoch & 1];
+#pragma unroll
+          for (int ci = 0; ci < 2; ++ci) {
+            const int cl = ci * 16 + slot;
+            if (cl < NC) put(buf + ks * N + cu * NC + cl, hidden_act(v[ci], a.act), c.epoch);
+          }
+        }
+        gather<MAXG>(c, R * N, xin);
+      } else {
+        kout[0] = tanhf(v[0]);
+        kout[1] = tanhf(v[1]);
+      }
+    }
+  };
+
+  if (a.mode == MODE_FEVAL) {
+    float kk[2];
+    feval(y, kk);
+    if (row_valid) {
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci)
+        if (colv[ci]) a.y_out[(size_t)grow * F + colg[ci]] = kk[ci];
+    }
+    return;
+  }
+
+  const int S = a.tab.stages;
+  const float inv_order = -1.f / (float)a.tab.order;
+  const int n_int = seq_mode ? a.P : 1;
+  int n_steps = 0, n_acc = 0;
+
+  for (int it = 0; it < n_int && !c.failed; ++it) {
+    // ======================= ODE phase =======================
+    if (a.mode != MODE_RNN_ONLY) {
+      float t = 0.f, t1 = 0.f;
+      if (row_valid) {
+        if (seq_mode) {
+          const float* tr = a.ts + (size_t)row_b * (a.P + 1);
+          const float base = a.ts_relative ? tr[0] : 0.f;
+          t = tr[it] - base;
+          t1 = tr[it + 1] - base;
+        } else {
+          t = a.t0[grow];
+          t1 = a.t1[grow];
+        }
+      }
+      const bool fixed = (a.tab.has_err == 0 && a.nsub > 0);
+      float dt, dtn = a.dt0;
+      bool last = false, running;
+      int sub_left = a.nsub;
+      if (fixed) {
+        dt = (t1 - t) / (float)a.nsub;
+        running = row_valid;
+      } else {
+        const float span = t1 - t;
+        last = dtn >= span;
+        dt = last ? span : dtn;
+        running = row_valid && (t < t1);
+      }
+      float k[7][2];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) k[j][0] = k[j][1] = 0.f;
+      bool have_k1 = false;
+      int guard = 0;
+      while (__syncthreads_or((running && has_row) ? 1 : 0)) {
+        if (c.failed) break;
+        if (++guard > a.max_steps) {
+          if (tid == 0) atomicCAS(c.status, 0, ST_MAX_STEPS);
+          break;
+        }
+        float sv[2] = {y[0], y[1]};
+        for (int s = 0; s < S; ++s) {
+          if (s == 0 && have_k1) continue;
+          if (s > 0) {
+            float a0 = 0.f, a1 = 0.f;
+            bool first = true;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+              if (j < s) {
+                const float co = a.tab.a[s][j];
+                if (co != 0.f) {
+                  // same association as the oracle: acc = k_j*a_sj summed left to right
+                  a0 = first ? k[j][0] * co : a0 + k[j][0] * co;
+                  a1 = first ? k[j][1] * co : a1 + k[j][1] * co;
+                  first = false;
+                }
+              }
+            }
+            sv[0] = y[0] + dt * a0;
+            sv[1] = y[1] + dt * a1;
+          }
+          float ko[2];
+          feval(sv, ko);
+#pragma unroll
+          for (int j = 0; j < 7; ++j)
+            if (j == s) {
+              k[j][0] = ko[0];
+              k[j][1] = ko[1];
+            }
+        }
+        // y1 = y + dt * sum b_j k_j   (FSAL: b_last = 0 and the sum equals the last stage's argument)
+        float y1[2], er[2];
+        {
+          float s0 = 0.f, s1 = 0.f, e0 = 0.f, e1 = 0.f;
+          bool fb = true, fe = true;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            if (j < S) {
+              const float bj = a.tab.b[j];
+              if (bj != 0.f) {
+                s0 = fb ? k[j][0] * bj : s0 + k[j][0] * bj;
+                s1 = fb ? k[j][1] * bj : s1 + k[j][1] * bj;
+                fb = false;
+              }
+              const float ej = a.tab.e[j];
+              if (a.tab.has_err && ej != 0.f) {
+                e0 = fe ? k[j][0] * ej : e0 + k[j][0] * ej;
+                e1 = fe ? k[j][1] * ej : e1 + k[j][1] * ej;
+                fe = false;
+              }
+            }
+          }
+          y1[0] = y[0] + dt * s0;
+          y1[1] = y[1] + dt * s1;
+          er[0] = dt * e0;
+          er[1] = dt * e1;
+        }
+        bool accept = true;
+        if (a.tab.has_err) {
+          // per-row RMS of err / (atol + rtol*max(|y0|,|y1|)) over all F columns (torchode rms_norm)
+          float q = 0.f;
+#pragma unroll
+          for (int ci = 0; ci < 2; ++ci) {
+            if (colv[ci]) {
+              const float bound = a.atol + a.rtol * fmaxf(fabsf(y[ci]), fabsf(y1[ci]));
+              const float z = er[ci] / bound;
+              q += z * z;
+            }
+          }
+          q += __shfl_xor(q, 16, 64);
+          q += __shfl_xor(q, 32, 64);
+          __syncthreads();  // red/nrm free
+          if ((tid & 63) < 16) red[(tid >> 6) * 16 + ks] = q;
+          __syncthreads();
+          ++c.epoch;
+          if (tid < R) {
+            const float s = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+            put(c.xb[c.epoch & 1] + tid * INTEG_MEMBERS + cu, s, c.epoch);
+          }
+          gather<MAXG>(c, R * INTEG_MEMBERS, nrm);
+          float tot = 0.f;
+          const int rr = has_row ? ks : 0;
+          for (int m = 0; m < INTEG_MEMBERS; ++m) tot += nrm[rr * INTEG_MEMBERS + m];
+          const float ratio = sqrtf(tot / (float)F);
+          accept = ratio < 1.0f;
+          float factor = 0.9f * powf(ratio, inv_order);
+          factor = fminf(fmaxf(factor, 0.2f), 10.0f);
+          dtn = dt * factor;
+        } else {
+          dtn = dt;
+        }
+        const bool upd = accept && running;
+        if (running) ++n_steps;
+        if (upd) {
+          ++n_acc;
+          y[0] = y1[0];
+          y[1] = y1[1];
+          if (a.tab.fsal) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+              if (j == S - 1) {
+                k[0][0] = k[j][0];
+                k[0][1] = k[j][1];
+              }
+          }
+        }
+        if (fixed) {
+          if (--sub_left <= 0) running = false;
+        } else {
+          if (upd) t = last ? t1 : t + dt;
+          running = row_valid && (t < t1);
+          const float span = t1 - t;
+          last = dtn >= span;
+          dt = last ? span : dtn;
+        }
+        have_k1 = a.tab.fsal != 0;
+      }
+      if (!seq_mode) break;
+    }
+    if (!seq_mode || c.failed) break;
+
+    // ======================= RNN phase =======================
+    // 1. all-gather the evolved states h~ [R][F] -> hst
+    ++c.epoch;
+    if (has_row) {
+      u64* buf = c.xb[c.epoch & 1];
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci)
+        if (colv[ci]) put(buf + ks * F + colg[ci], y[ci], c.epoch);
+    }
+    gather<MAXG>(c, R * F, hst);
+    const int NCV = a.rnn_vcols * NCF;
+    for (int l = 0; l < a.L; ++l) {
+      if (l == 0) {
+        __syncthreads();
+        for (int i = tid; i < BPG * F; i += 256) {
+          const int bi = i / F;
+          const int b = a.b_begin + g * BPG + bi;
+          xin[i] = (b < a.b_end) ? a.fused[((size_t)b * a.P + it) * F + (i - bi * F)] : 0.f;
+        }
+        __syncthreads();
+      }
+      const float* wsl = a.rw[l] + (size_t)cu * NCV * 2 * F;
+      for (int pass = 0; pass * 32 < NCV; ++pass) {
+        float acc[2][RT];
+        layer<RT, false>(wsl, NCV, F, xin, F, F, hst + (size_t)l * BPG * F, F, BPG, pass * 32 + slot, ks, acc);
+        if (ks < BPG) {
+#pragma unroll
+          for (int ci = 0; ci < 2; ++ci) {
+            const int cl = pass * 32 + ci * 16 + slot;
+            if (cl < NCV) pre[cl * RT + ks] = pick<RT>(acc[ci], ks);
+          }
+        }
+      }
+      __syncthreads();
+      float hn[2] = {0.f, 0.f};
+      if (ks < BPG) {
+        const int b = a.b_begin + g * BPG + ks;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+          const int ul = ci * 16 + slot;
+          if (ul >= NCF) continue;
+          const int ug = cu * NCF + ul;
+          const float* rb = a.rb[l];
+          float h;
+          if (a.rnn_type == 0) {
+            h = tanhf(pre[ul * RT + ks] + rb[ug]);
+          } else {
+            const float rg = sigmoidf_(pre[ul * RT + ks] + rb[ug]);
+            const float zg = sigmoidf_(pre[(NCF + ul) * RT + ks] + rb[F + ug]);
+            const float ng = tanhf(pre[(2 * NCF + ul) * RT + ks] + rb[2 * F + ug] +
+                                   rg * (pre[(3 * NCF + ul) * RT + ks] + rb[3 * F + ug]));
+            const float hp = hst[((size_t)l * BPG + ks) * F + ug];
+            h = (1.f - zg) * ng + zg * hp;
+          }
+          hn[ci] = h;
+          mv[(l * BPG + ks) * 32 + ul] = h;
+          if (l == a.L - 1 && b < a.b_end) a.out_seq[((size_t)b * a.P + it) * F + ug] = h;
+        }
+      }
+      if (l + 1 < a.L) {
+        ++c.epoch;
+        if (ks < BPG) {
+          u64* buf = c.xb[c.epoch & 1];
+#pragma unroll
+          for (int ci = 0; ci < 2; ++ci) {
+            const int ul = ci * 16 + slot;
+            if (ul < NCF) put(buf + ks * F + cu * NCF + ul, hn[ci], c.epoch);
+          }
+        }
+        gather<MAXG>(c, BPG * F, xin);
+      }
+    }
+    __syncthreads();
+    if (has_row) {
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci)
+        if (colv[ci]) y[ci] = mv[ks * 32 + ci * 16 + slot];
+    }
+    __syncthreads();
+  }
+
+  // ---- outputs
+  if (row_valid && !c.failed) {
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      if (!colv[ci]) continue;
+      if (seq_mode) a.hT[(size_t)grow * F + colg[ci]] = y[ci];
+      else a.y_out[(size_t)grow * F + colg[ci]] = y[ci];
+    }
+    if (a.stats && cu == 0 && slot == 0) {
+      a.stats[2 * grow] = n_steps;
+      a.stats[2 * grow + 1] = n_acc;
+    }
+  }
+}
+
+int launch_integrator(const IntegArgs& a, int rt, size_t lds_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(INTEG_GROUPS * INTEG_MEMBERS), block(256);
+  const int max_dyn = 160 * 1024 - 1024;  // the kernel also owns a little static LDS
+  static bool attr4 = false, attr8 = false;
+  hipError_t e = hipSuccess;
+  (void)hipGetLastError();  // do not inherit a stale error from an unrelated call
+  if (rt <= 4) {
+    if (!attr4) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+      if (e != hipSuccess) return (int)e;
+      attr4 = true;
+    }
+    hipLaunchKernelGGL(integrator_kernel<4>, grid, block, lds_bytes, st, a);
+  } else {
+    if (!attr8) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_kernel<8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+      if (e != hipSuccess) return (int)e;
+      attr8 = true;
+    }
+    hipLaunchKernelGGL(integrator_kernel<8>, grid, block, lds_bytes, st, a);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,319 @@
+"""Host-side mirror of the reference's model surface for the hot path.
+
+``DeepVIO(opt).forward(img, imu, timestamps, hc=None) -> (poses, h_T)`` has the signature, tensor
+layouts, attribute names (``Image_net``, ``Inertial_net``, ``Pose_net``, ``opt``) and ``state_dict``
+keys of the reference class (reference src/models/DeepVIO.py:37-68), so the reference's callers
+(scripts/train_model.py:69 in eval, src/data/KITTI_eval.py:141) can use it unchanged and reference
+checkpoints load with ``load_state_dict``.  The sub-modules are *parameter containers only*: all
+arithmetic runs in libodevio.so (hand-written HIP for gfx950) through the C ABI of
+``include/odevio.h``.  There is no PyTorch compute path and no CPU path: without the library, or
+on CPU tensors, ``forward`` raises.
+
+Error behaviour follows the reference: ``ValueError`` for an unknown solver / RNN type /
+activation (PoseODERNN.py:136,146; ODEFunc.py:34), ``NotImplementedError`` for ``ltc``
+(DeepVIO.py:59); an unknown ``model_type`` raises ``ValueError`` instead of silently leaving
+``Pose_net = None``.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib, weights
+
+
+def _conv_block(cin, cout, k, stride):
+    # same child indices as the reference's conv() (Encoder.py:8-22): 0 = Conv2d(no bias), 1 = BatchNorm2d
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False), nn.BatchNorm2d(cout),
+                         nn.LeakyReLU(0.1), nn.Dropout(0.0))
+
+
+class _ImageNet(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        for name, cin, cout, k, s in weights.IMAGE_CONVS:
+            setattr(self, name, _conv_block(cin, cout, k, s))
+        oh, ow = weights.encoder_out_hw(opt.img_h, opt.img_w)
+        self.visual_head = nn.Linear(1024 * oh * ow, opt.v_f_len)
+
+
+class _InertialNet(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        layers = []
+        for _, cin, cout in weights.IMU_CONVS:
+            layers += [nn.Conv1d(cin, cout, 3, padding=1), nn.BatchNorm1d(cout), nn.LeakyReLU(0.1), nn.Dropout(0.0)]
+        self.encoder_conv = nn.Sequential(*layers)
+        self.proj = nn.Linear(256 * weights.IMU_WINDOW, opt.i_f_len)
+
+
+class _Fuse(nn.Module):
+    def __init__(self, f_len, method):
+        super().__init__()
+        if method == "soft":
+            self.net = nn.Sequential(nn.Linear(f_len, f_len))
+        elif method == "hard":
+            self.net = nn.Sequential(nn.Linear(f_len, 2 * f_len))
+
+
+class _OdeFunc(nn.Module):
+    def __init__(self, f_len, hidden, n_hidden, activation):
+        super().__init__()
+        if activation not in _lib.ACTIVATIONS:
+            raise ValueError(f"Activation function {activation} not supported")
+        dims = [f_len] + [hidden] * n_hidden + [f_len]
+        layers = []
+        for i in range(n_hidden + 1):
+            layers += [nn.Linear(dims[i], dims[i + 1]), nn.Identity()]  # odd slots: activations (no parameters)
+        self.net = nn.Sequential(*layers)
+
+
+class _PoseNet(nn.Module):
+    """Parameter container for PoseODERNN / PoseRNN (reference PoseODERNN.py:39-68, PoseRNN.py:38-51)."""
+
+    def __init__(self, opt, with_ode):
+        super().__init__()
+        self.f_len = opt.v_f_len + opt.i_f_len
+        if with_ode:
+            if opt.ode_solver not in _lib.SOLVERS:
+                raise ValueError(f"Solver {opt.ode_solver} not supported")
+            self.ode_func = _OdeFunc(self.f_len, opt.ode_hidden_dim, opt.ode_fn_num_layers, opt.ode_activation_fn)
+        if opt.ode_rnn_type == "rnn":
+            self.rnn = nn.RNN(self.f_len, self.f_len, opt.rnn_num_layers, batch_first=True)
+        elif opt.ode_rnn_type == "gru":
+            self.rnn = nn.GRU(self.f_len, self.f_len, opt.rnn_num_layers, batch_first=True)
+        else:
+            raise ValueError(f"RNN type {opt.ode_rnn_type} not supported")
+        self.fuse = _Fuse(self.f_len, opt.fuse_method)
+        self.regressor = nn.Sequential(nn.Linear(self.f_len, 128), nn.LeakyReLU(0.1), nn.Linear(128, 6))
+
+    def get_regressor_params(self):
+        return self.regressor.parameters()
+
+    def get_other_params(self):
+        return [p for n, p in self.named_parameters() if not n.startswith("regressor")]
+
+
+class DeepVIO(nn.Module):
+    def __init__(self, opt, seed=None):
+        super().__init__()
+        if opt.model_type == "ltc":
+            raise NotImplementedError("LTC model not implemented yet")
+        if opt.model_type in ("cde", "rde"):
+            raise NotImplementedError(f"model_type {opt.model_type!r}: the Neural-CDE path is not built yet (DESIGN.md section 9)")
+        if opt.model_type not in ("ode-rnn", "rnn"):
+            raise ValueError(f"model_type {opt.model_type!r} not supported")
+        if opt.fuse_method not in ("cat", "soft", "hard"):
+            raise ValueError(f"fuse_method {opt.fuse_method!r} not supported")
+        if getattr(opt, "dtype", "fp32") != "fp32":
+            raise ValueError("only --dtype fp32 is built (the 1e-4 parity bar applies to fp32)")
+        self.opt = opt
+        self.Image_net = _ImageNet(opt)
+        self.Inertial_net = _InertialNet(opt)
+        self.Pose_net = _PoseNet(opt, with_ode=(opt.model_type == "ode-rnn"))
+        self._plan = None
+        self._plan_sig = None
+        self._lib = _lib.load()  # raises if the HIP library is missing: no silent fallback
+        # the reference constructor leaves a random model behind (DeepVIO.py:43); ours is seeded
+        sd = weights.make_state_dict(opt, seed=getattr(opt, "seed", 0) if seed is None else seed)
+        self.load_state_dict(sd, strict=True)
+        self.eval()
+
+    # ------------------------------------------------------------------ plan management
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts reference checkpoints: drops the ``Pose_net.solver.*`` aliases and a ``module.`` prefix."""
+        self._plan_sig = None
+        return super().load_state_dict(weights.filter_reference_state_dict(state_dict), strict=strict, **kw)
+
+    def _signature(self):
+        sig = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            sig.append((t.data_ptr(), t._version))
+        return tuple(sig)
+
+    def _config(self):
+        o = self.opt
+        c = _lib.OdevioConfig()
+        c.struct_size = ctypes.sizeof(_lib.OdevioConfig)
+        c.model_type = _lib.MODEL_TYPES[o.model_type]
+        c.img_h, c.img_w, c.v_f_len, c.i_f_len = o.img_h, o.img_w, o.v_f_len, o.i_f_len
+        c.fuse_method = _lib.FUSE_METHODS.get(o.fuse_method, 0)  # "hard": mask on the host, cat on the device
+        c.ode_hidden_dim, c.ode_fn_num_layers = o.ode_hidden_dim, o.ode_fn_num_layers
+        c.ode_activation = _lib.ACTIVATIONS[o.ode_activation_fn]
+        c.ode_solver = _lib.SOLVERS[o.ode_solver]
+        c.ode_substeps = getattr(o, "ode_substeps", 1)
+        c.rnn_type = _lib.RNN_TYPES[o.ode_rnn_type]
+        c.rnn_num_layers = o.rnn_num_layers
+        # torchode IntegralController(atol=1e-6, rtol=1e-2), dt0 = 1e-4 (PoseODERNN.py:57,72)
+        c.atol, c.rtol, c.dt0 = getattr(o, "ode_atol", 1e-6), getattr(o, "ode_rtol", 1e-2), getattr(o, "ode_dt0", 1e-4)
+        c.max_steps = getattr(o, "ode_max_steps", 200000)
+        return c
+
+    def _ensure_plan(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("odevio_amd.DeepVIO runs on an MI355X only: move the model with .cuda() (no CPU path)")
+        sig = self._signature()
+        if self._plan is not None and sig == self._plan_sig:
+            return
+        self._destroy_plan()
+        sd = {k: v for k, v in self.state_dict().items() if v.is_floating_point()}
+        keep = []  # keep contiguous fp32 views alive during the call
+        arr = (_lib.OdevioTensor * len(sd))()
+        for i, (k, v) in enumerate(sd.items()):
+            t = v.detach().to(torch.float32).contiguous()
+            keep.append(t)
+            arr[i].name = k.encode()
+            arr[i].data = t.data_ptr()
+            arr[i].numel = t.numel()
+        plan = ctypes.c_void_p()
+        cfg = self._config()
+        with torch.cuda.device(dev):
+            torch.cuda.current_stream().synchronize()
+            _lib.check(self._lib.odevio_plan_create(ctypes.byref(cfg), arr, len(sd), self._stream(), ctypes.byref(plan)))
+        self._plan, self._plan_sig = plan, sig
+
+    def _destroy_plan(self):
+        if getattr(self, "_plan", None) is not None:
+            self._lib.odevio_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self._destroy_plan()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _dev(t, name):
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a device tensor (no CPU path)")
+        return t.detach().to(torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ the reference surface
+    def forward(self, img, imu, timestamps, hc=None):
+        """img [B,S,3,H,W], imu [B,10(S-1)+1(+tail),6], timestamps [B,S], hc None | [L,B,F] -> (poses [B,S-1,6], h_T [L,B,F])."""
+        self._ensure_plan()
+        if self.opt.fuse_method == "hard":
+            fv, fi = self.image_encoder(img), self.imu_encoder(imu)
+            return self.pose_net(fv, fi, timestamps, hc)
+        img, imu, ts = self._dev(img, "img"), self._dev(imu, "imu"), self._dev(timestamps, "timestamps")
+        B, S = img.shape[0], img.shape[1]
+        L, F = self.opt.rnn_num_layers, self.opt.v_f_len + self.opt.i_f_len
+        hcp = None
+        if hc is not None:
+            hc = self._dev(hc, "hc")
+            if tuple(hc.shape) != (L, B, F):
+                raise ValueError(f"hc must be [{L},{B},{F}], got {tuple(hc.shape)}")
+            hcp = hc.data_ptr()
+        poses = torch.empty(B, S - 1, 6, device=img.device, dtype=torch.float32)
+        h_T = torch.empty(L, B, F, device=img.device, dtype=torch.float32)
+        with torch.cuda.device(img.device):
+            _lib.check(self._lib.odevio_forward(self._plan, img.data_ptr(), imu.data_ptr(), imu.shape[1], ts.data_ptr(),
+                                                hcp, B, S, poses.data_ptr(), h_T.data_ptr(), None, self._stream()))
+        return poses, h_T
+
+    # ------------------------------------------------------------------ component entry points (tests, bench)
+    def image_encoder(self, img):
+        self._ensure_plan()
+        img = self._dev(img, "img")
+        B, S = img.shape[0], img.shape[1]
+        fv = torch.empty(B, S - 1, self.opt.v_f_len, device=img.device, dtype=torch.float32)
+        _lib.check(self._lib.odevio_image_encoder_fwd(self._plan, img.data_ptr(), B, S, fv.data_ptr(), self.opt.v_f_len,
+                                                      self._stream()))
+        return fv
+
+    def conv_block(self, layer, x, B, S):
+        """One conv block (kernel-level parity): layer 0 takes img [B,S,3,H,W]; others take NHWC activations."""
+        self._ensure_plan()
+        x = self._dev(x, "x")
+        h, w = self.opt.img_h, self.opt.img_w
+        for _, _, cout, k, s in weights.IMAGE_CONVS[:layer + 1]:
+            h, w = weights.conv_out(h, k, s), weights.conv_out(w, k, s)
+        out = torch.empty(B * (S - 1), h, w, cout, device=x.device, dtype=torch.float32)
+        _lib.check(self._lib.odevio_conv_block_fwd(self._plan, layer, x.data_ptr(), B, S, out.data_ptr(), self._stream()))
+        return out
+
+    def imu_encoder(self, imu):
+        self._ensure_plan()
+        imu = self._dev(imu, "imu")
+        B, T = imu.shape[0], imu.shape[1]
+        fi = torch.empty(B, (T - 1) // 10, self.opt.i_f_len, device=imu.device, dtype=torch.float32)
+        _lib.check(self._lib.odevio_imu_encoder_fwd(self._plan, imu.data_ptr(), B, T, fi.data_ptr(), self.opt.i_f_len,
+                                                    self._stream()))
+        return fi
+
+    def fuse(self, fv, fi):
+        self._ensure_plan()
+        fv, fi = self._dev(fv, "fv"), self._dev(fi, "fi")
+        if self.opt.fuse_method == "hard":
+            # stochastic Gumbel mask (FusionModule.py:24-29): host-side torch on the device, no parity claim
+            cat = torch.cat((fv, fi), -1)
+            w = torch.nn.functional.linear(cat, self.Pose_net.fuse.net[0].weight, self.Pose_net.fuse.net[0].bias)
+            mask = torch.nn.functional.gumbel_softmax(w.view(*cat.shape, 2), tau=1, hard=True, dim=-1)
+            return cat * mask[..., 0]
+        P = fv.shape[0] * fv.shape[1]
+        out = torch.empty(fv.shape[0], fv.shape[1], fv.shape[2] + fi.shape[2], device=fv.device, dtype=torch.float32)
+        _lib.check(self._lib.odevio_fuse_fwd(self._plan, fv.data_ptr(), fi.data_ptr(), P, out.data_ptr(), self._stream()))
+        return out
+
+    def ode_func(self, y):
+        self._ensure_plan()
+        y = self._dev(y, "y")
+        out = torch.empty_like(y)
+        _lib.check(self._lib.odevio_ode_func(self._plan, y.data_ptr(), y.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def ode_steps(self, y, t0, t1, solver=None, substeps=0, return_stats=False):
+        """Integrate rows of y from t0[r] to t1[r] (PoseODERNN.evolve_state)."""
+        self._ensure_plan()
+        y, t0, t1 = self._dev(y, "y"), self._dev(t0, "t0"), self._dev(t1, "t1")
+        if solver is not None and solver not in _lib.SOLVERS:
+            raise ValueError(f"Solver {solver} not supported")
+        out = torch.empty_like(y)
+        stats = torch.zeros(y.shape[0], 2, device=y.device, dtype=torch.int32)
+        _lib.check(self._lib.odevio_ode_steps(self._plan, y.data_ptr(), t0.data_ptr(), t1.data_ptr(), y.shape[0],
+                                              -1 if solver is None else _lib.SOLVERS[solver], substeps, out.data_ptr(),
+                                              stats.data_ptr(), self._stream()))
+        return (out, stats) if return_stats else out
+
+    def pose_net(self, fv, fi, timestamps, hc=None, return_stats=False):
+        """PoseODERNN.forward / PoseRNN.forward on encoder features."""
+        self._ensure_plan()
+        fused = self.fuse(fv, fi)
+        ts = self._dev(timestamps, "timestamps")
+        B, P, F = fused.shape
+        L = self.opt.rnn_num_layers
+        hcp = None
+        if hc is not None:
+            hc = self._dev(hc, "hc")
+            hcp = hc.data_ptr()
+        poses = torch.empty(B, P, 6, device=fused.device, dtype=torch.float32)
+        h_T = torch.empty(L, B, F, device=fused.device, dtype=torch.float32)
+        stats = torch.zeros(L * B, 2, device=fused.device, dtype=torch.int32)
+        # cat/soft were applied by fuse(); hand the fused rows to the integrator
+        _lib.check(self._lib.odevio_ode_rnn_fwd(self._plan, fused.data_ptr(), ts.data_ptr(), hcp, B, P, poses.data_ptr(),
+                                                h_T.data_ptr(), stats.data_ptr(), self._stream()))
+        return (poses, h_T, stats) if return_stats else (poses, h_T)
+
+    STAGES = ("conv1", "conv2_6", "visual_head", "imu_fuse", "integrator", "regressor")
+
+    def profile_enable(self, on=True):
+        """Record HIP events at the stage boundaries of every following forward (on the current stream)."""
+        self._ensure_plan()
+        _lib.check(self._lib.odevio_profile_enable(self._plan, 1 if on else 0))
+
+    def profile_read(self):
+        """Stage durations (ms) of the last forward, keyed by ``STAGES``."""
+        ms = (ctypes.c_float * len(self.STAGES))()
+        _lib.check(self._lib.odevio_profile_read(self._plan, ctypes.cast(ms, ctypes.c_void_p)))
+        return dict(zip(self.STAGES, [float(x) for x in ms]))
+
+    def check(self):
+        """Synchronise and raise if the last integrator launch reported a timeout / step-budget error."""
+        self._ensure_plan()
+        _lib.check(self._lib.odevio_check(self._plan, self._stream()))

@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Every test here needs a real MI355X (``-m gpu``).  The bar is the north star's: fp32 results within
+1e-4 relative (max|gpu - oracle| / max|oracle| per tensor); the tolerance is stated at each assert.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from odevio_amd import default_opt, synth, weights
+from oracle import odevio_oracle as oc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def make_model(opt, seed, randomize=True):
+    from odevio_amd import DeepVIO
+    model = DeepVIO(opt, seed=seed)
+    sd = weights.make_state_dict(opt, seed=seed, randomize_stats=randomize)
+    model.load_state_dict(sd)
+    return model.cuda(), sd
+
+
+def assert_close(got, ref, tol=TOL, what=""):
+    err = oc.rel_err(got, ref)
+    assert err < tol, f"{what}: rel err {err:.3e} >= {tol}"
+    return err
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel level
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hw", [(64, 128), (96, 160)])
+def test_conv_blocks_one_by_one(dev, hw):
+    """Every conv block alone, fed with the ORACLE's input for that block (errors cannot compound)."""
+    H, W = hw
+    opt = default_opt(img_h=H, img_w=W)
+    model, sd = make_model(opt, seed=21)
+    B, S = 2, 3
+    img = synth.images(B, S, H, W, seed=5)
+    _, inter = oc.image_encoder(sd, img, return_intermediate=True)
+    names = [n for n, _, _ in oc.IMAGE_CONVS]
+    x = img.cuda()
+    for i, name in enumerate(names):
+        out = model.conv_block(i, x, B, S)
+        assert_close(out, nhwc(inter[name]), what=name)
+        x = nhwc(inter[name]).cuda()
+    model.check()
+
+
+def test_image_encoder_ragged_sizes(dev):
+    # image sizes that are not multiples of the tile sizes exercise every bounds path
+    opt = default_opt(img_h=72, img_w=136)
+    model, sd = make_model(opt, seed=22)
+    img = synth.images(1, 4, 72, 136, seed=6)
+    assert_close(model.image_encoder(img.cuda()), oc.image_encoder(sd, img), what="fv")
+
+
+def test_image_encoder_golden_full_size(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "image_encoder_full.npz"))
+    opt = default_opt()
+    model, _ = make_model(opt, seed=int(g["wseed"]), randomize=bool(g["randomize_stats"]))
+    img = synth.images(int(g["B"]), int(g["S"]), 256, 512, seed=int(g["iseed"]))
+    assert_close(model.image_encoder(img.cuda()), torch.from_numpy(g["fv"]), what="fv vs reference")
+
+
+def test_image_encoder_golden_small(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "image_encoder_small.npz"))
+    opt = default_opt(img_h=int(g["H"]), img_w=int(g["W"]))
+    model, _ = make_model(opt, seed=int(g["wseed"]), randomize=True)
+    img = synth.images(int(g["B"]), int(g["S"]), int(g["H"]), int(g["W"]), seed=int(g["iseed"]))
+    assert_close(model.image_encoder(img.cuda()), torch.from_numpy(g["fv"]), what="fv vs reference")
+    c1 = model.conv_block(0, img.cuda(), int(g["B"]), int(g["S"]))  # NHWC
+    assert_close(c1.permute(0, 3, 1, 2)[:, ::8, ::8, ::8], torch.from_numpy(g["conv1_sample"]), what="conv1 vs reference")
+
+
+def test_inertial_encoder(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "inertial_encoder.npz"))
+    opt = default_opt(img_h=64, img_w=128)
+    model, sd = make_model(opt, seed=int(g["wseed"]))
+    real = torch.from_numpy(g["imu04"])
+    for T in (11, 21, 51, 101, 105):
+        fi = model.imu_encoder(real[:, :T].cuda())
+        assert fi.shape == (1, (T - 1) // 10, 256)
+        assert_close(fi, torch.from_numpy(g[f"fi_T{T}"]), what=f"fi T={T} vs reference")
+    syn = synth.imu(3, 11, seed=5)
+    assert_close(model.imu_encoder(syn.cuda()), torch.from_numpy(g["fi_syn"]), what="fi synthetic vs reference")
+    big = synth.imu(16, 11, seed=9)
+    assert_close(model.imu_encoder(big.cuda()), oc.inertial_encoder(sd, big), what="fi B=16 vs oracle")
+
+
+@pytest.mark.parametrize("method", ["cat", "soft"])
+def test_fusion(dev, golden_dir, method):
+    g = np.load(os.path.join(golden_dir, "fusion.npz"))
+    opt = default_opt(img_h=64, img_w=128, fuse_method=method)
+    model, _ = make_model(opt, seed=int(g["wseed"]))
+    out = model.fuse(torch.from_numpy(g["fv"]).cuda(), torch.from_numpy(g["fi"]).cuda())
+    assert_close(out, torch.from_numpy(g[method]), what=f"fuse {method} vs reference")
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu", "leaky_relu", "softplus"])
+@pytest.mark.parametrize("n,H", [(3, 512), (2, 1024)])
+def test_odefunc(dev, golden_dir, act, n, H):
+    g = np.load(os.path.join(golden_dir, "odefunc.npz"))
+    opt = default_opt(img_h=64, img_w=128, ode_activation_fn=act, ode_fn_num_layers=n, ode_hidden_dim=H)
+    model, sd = make_model(opt, seed=int(g["wseed"]))
+    y = torch.from_numpy(g["y"])
+    assert_close(model.ode_func(y.cuda()), torch.from_numpy(g[f"f_{act}_{n}_{H}"]), what="f(y) vs reference")
+    yy = torch.randn(37, 768, generator=torch.Generator().manual_seed(3)) * 0.8  # ragged row count, several groups
+    assert_close(model.ode_func(yy.cuda()), oc.ode_func(sd, yy, n, act), what="f(y) 37 rows vs oracle")
+    model.check()
+
+
+# ------------------------------------------------------------------------------------------------
+# integrator
+# ------------------------------------------------------------------------------------------------
+def _rows_problem(rows, seed):
+    g = torch.Generator().manual_seed(seed)
+    y0 = torch.randn(rows, 768, generator=g) * 0.5
+    t0 = torch.rand(rows, generator=g) * 3.0
+    gaps = torch.tensor([0.1, 0.2, 0.3, 0.5])[torch.randint(0, 4, (rows,), generator=g)]
+    return y0, t0, t0 + gaps
+
+
+@pytest.mark.parametrize("solver,substeps", [("rk4", 1), ("rk4", 3), ("rk4_classic", 2), ("dopri5", 1), ("tsit5", 1),
+                                             ("heun", 1)])
+@pytest.mark.parametrize("rows", [32, 5])
+def test_ode_steps(dev, solver, substeps, rows):
+    opt = default_opt(img_h=64, img_w=128, ode_solver=solver, ode_substeps=substeps)
+    model, sd = make_model(opt, seed=31)
+    y0, t0, t1 = _rows_problem(rows, seed=rows)
+    got, stats = model.ode_steps(y0.cuda(), t0.cuda(), t1.cuda(), return_stats=True)
+    model.check()
+    tr = {}
+    f = lambda y: oc.ode_func(sd, y, opt.ode_fn_num_layers, opt.ode_activation_fn)
+    ref = oc.evolve_state(f, y0, t0, t1, solver, substeps, trace=tr)
+    assert_close(got, ref, what=f"{solver} state")
+    # identical step sequences: attempted and accepted step counts per row
+    assert torch.equal(stats[:, 0].cpu().long(), tr["n_steps"]), (stats[:, 0].cpu(), tr["n_steps"])
+    assert torch.equal(stats[:, 1].cpu().long(), tr["n_accepted"])
+
+
+def test_euler_reference_semantics(dev):
+    # torchode's controller never changes dt without an error estimate: 1e-4 steps to the end
+    opt = default_opt(img_h=64, img_w=128, ode_solver="euler")
+    model, sd = make_model(opt, seed=32)
+    y0 = torch.randn(4, 768, generator=torch.Generator().manual_seed(1)) * 0.5
+    t0 = torch.zeros(4)
+    t1 = torch.tensor([0.0105, 0.02, 0.0033, 0.01])
+    got, stats = model.ode_steps(y0.cuda(), t0.cuda(), t1.cuda(), return_stats=True)
+    model.check()
+    f = lambda y: oc.ode_func(sd, y, 3, "tanh")
+    tr = {}
+    ref = oc.evolve_state(f, y0, t0, t1, "euler", trace=tr)
+    assert_close(got, ref, what="euler state")
+    assert torch.equal(stats[:, 0].cpu().long(), tr["n_steps"])
+
+
+def test_ode_steps_linearity_of_time_shift(dev):
+    # autonomous field: shifting both ends of every interval by a constant changes nothing but rounding of t
+    opt = default_opt(img_h=64, img_w=128, ode_solver="dopri5")
+    model, _ = make_model(opt, seed=33)
+    y0, t0, t1 = _rows_problem(16, seed=2)
+    a = model.ode_steps(y0.cuda(), (t0 * 0).cuda(), (t1 - t0).cuda())
+    b = model.ode_steps(y0.cuda(), (t0 * 0 + 64.0).cuda(), (t1 - t0 + 64.0).cuda())
+    assert_close(a, b, tol=1e-3, what="time-shift invariance")
+
+
+@pytest.mark.parametrize("rnn_type", ["rnn", "gru"])
+@pytest.mark.parametrize("L", [2, 3])
+@pytest.mark.parametrize("method", ["cat", "soft"])
+def test_pose_rnn_golden(dev, golden_dir, rnn_type, L, method):
+    """fuse -> RNN stack -> regressor (no ODE) against the REAL reference PoseRNN, incl. carried hc."""
+    g = np.load(os.path.join(golden_dir, "pose_rnn.npz"))
+    opt = default_opt(img_h=64, img_w=128, model_type="rnn", ode_rnn_type=rnn_type, rnn_num_layers=L, fuse_method=method)
+    model, _ = make_model(opt, seed=int(g["wseed"]))
+    fv, fi, ts = (torch.from_numpy(g[k]).cuda() for k in ("fv", "fi", "ts"))
+    key = f"{rnn_type}_{L}_{method}"
+    p1, h1 = model.pose_net(fv, fi, ts, None)
+    assert_close(p1, torch.from_numpy(g[key + "_pose1"]), what="pose1 vs reference")
+    assert_close(h1, torch.from_numpy(g[key + "_h1"]), what="h1 vs reference")
+    p2, h2 = model.pose_net(fv.flip(0), fi.flip(0), ts, h1)
+    assert_close(p2, torch.from_numpy(g[key + "_pose2"]), what="pose2 vs reference")
+    assert_close(h2, torch.from_numpy(g[key + "_h2"]), what="h2 vs reference")
+    model.check()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(ode_solver="rk4"),
+    dict(ode_solver="dopri5"),
+    dict(ode_solver="dopri5", ode_rnn_type="gru", fuse_method="soft"),
+    dict(ode_solver="tsit5", rnn_num_layers=3, ode_activation_fn="softplus", ode_fn_num_layers=2, ode_hidden_dim=1024,
+         fuse_method="soft"),  # the reference's own training recipe (scripts/run_training.sh:6-28) with tsit5
+    dict(ode_solver="heun", rnn_num_layers=1),
+])
+@pytest.mark.parametrize("B,drop", [(16, 0.0), (3, 0.5)])
+def test_pose_ode_rnn(dev, cfg, B, drop):
+    """The whole ODE-RNN loop on encoder features: regular and irregular (50 % drop) timestamps, ragged batch."""
+    opt = default_opt(img_h=64, img_w=128, **cfg)
+    model, sd = make_model(opt, seed=41)
+    g = torch.Generator().manual_seed(B)
+    fv = torch.randn(B, 10, 512, generator=g)
+    fi = torch.randn(B, 10, 256, generator=g)
+    ts = synth.timestamps(B, 11, drop=drop, seed=B, absolute=True)
+    poses, h, stats = model.pose_net(fv.cuda(), fi.cuda(), ts.cuda(), None, return_stats=True)
+    model.check()
+    tr = {}
+    ref_p, ref_h = oc.pose_ode_rnn(sd, fv, fi, ts, None, opt, trace=tr)
+    assert_close(poses, ref_p, what="poses")
+    assert_close(h, ref_h, what="h_T")
+    # Step sequences agree except where the embedded error estimate sits at the fp32 rounding floor
+    # (e.g. the all-zero initial state): there 0.9*ratio^(-1/5) moves between ~8 and the clamp of 10 with
+    # the last bits of tanh, so an interval may take one step more or fewer.  Allow 1 step per 5 intervals.
+    want = sum(t["n_steps"] for t in tr["intervals"])
+    diff = (stats[:, 0].cpu().long() - want).abs()
+    assert int(diff.max()) <= 2, (stats[:, 0].cpu(), want)
+    # streaming: carry h_T into the next window with absolute timestamps (reference KITTI_eval.py:141)
+    ts2 = ts + 1.0
+    p2, h2 = model.pose_net(fv.flip(1).cuda(), fi.flip(1).cuda(), ts2.cuda(), h)
+    r2, rh2 = oc.pose_ode_rnn(sd, fv.flip(1), fi.flip(1), ts2, ref_h, opt)
+    assert_close(p2, r2, tol=2e-4, what="poses (carried hc)")
+    assert_close(h2, rh2, tol=2e-4, what="h_T (carried hc)")
+
+
+# ------------------------------------------------------------------------------------------------
+# whole path
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("solver", ["rk4", "dopri5"])
+def test_deepvio_forward_small(dev, solver):
+    opt = default_opt(img_h=64, img_w=128, ode_solver=solver)
+    model, sd = make_model(opt, seed=51)
+    img, imu, ts = synth.batch(3, 5, 64, 128, drop=0.3, seed=8)
+    poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    ref_p, ref_h = oc.deepvio_forward(sd, img, imu, ts, None, opt)
+    assert poses.shape == (3, 4, 6) and h.shape == (2, 3, 768)
+    assert_close(poses, ref_p, what="poses")
+    assert_close(h, ref_h, what="h_T")
+
+
+def test_deepvio_forward_full_size(dev):
+    """KITTI-sized frames (256x512), B=2, S=4, RK4: the north star's parity bar on the real shapes."""
+    opt = default_opt(ode_solver="rk4")
+    model, sd = make_model(opt, seed=52, randomize=False)
+    img, imu, ts = synth.batch(2, 4, 256, 512, seed=9)
+    poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    ref_p, ref_h = oc.deepvio_forward(sd, img, imu, ts, None, opt)
+    e = assert_close(poses, ref_p, what="poses")
+    assert_close(h, ref_h, what="h_T")
+    # both fp32 paths should sit equally close to the fp64 truth
+    tru_p, _ = oc.deepvio_forward(sd, img, imu, ts, None, opt, dtype=torch.float64)
+    assert oc.rel_err(poses, tru_p) < TOL and oc.rel_err(ref_p, tru_p) < TOL, e
+
+
+def test_forward_is_deterministic_and_batch_independent(dev):
+    # size-independent properties: same inputs -> same bits; a sequence's poses do not depend on its batch mates
+    opt = default_opt(img_h=64, img_w=128, ode_solver="dopri5")
+    model, _ = make_model(opt, seed=53)
+    img, imu, ts = synth.batch(5, 4, 64, 128, drop=0.5, seed=10)
+    p1, h1 = model(img.cuda(), imu.cuda(), ts.cuda())
+    p2, h2 = model(img.cuda(), imu.cuda(), ts.cuda())
+    assert torch.equal(p1, p2) and torch.equal(h1, h2)
+    p3, _ = model(img[1:3].cuda(), imu[1:3].cuda(), ts[1:3].cuda())
+    assert_close(p3, p1[1:3], tol=1e-5, what="batch independence")
+
+
+def test_errors_are_loud(dev):
+    from odevio_amd import DeepVIO
+    with pytest.raises(ValueError):
+        DeepVIO(default_opt(ode_solver="rk45"))
+    with pytest.raises(ValueError):
+        DeepVIO(default_opt(ode_rnn_type="lstm"))
+    with pytest.raises(ValueError):
+        DeepVIO(default_opt(ode_activation_fn="gelu"))
+    with pytest.raises(NotImplementedError):
+        DeepVIO(default_opt(model_type="ltc"))
+    model = DeepVIO(default_opt(img_h=64, img_w=128)).cuda()
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 2, 3, 64, 128), torch.zeros(1, 11, 6), torch.zeros(1, 2))  # CPU tensors: no CPU path
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 3, 64, 128).cuda(), torch.zeros(1, 11, 6).cuda(), torch.zeros(1, 3).cuda())  # imu too short
