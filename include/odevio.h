@@ -134,6 +134,11 @@ int odevio_profile_enable(odevio_plan* plan, int32_t on);
 /* Waits for the last recorded forward and writes ODEVIO_N_STAGES durations in milliseconds. */
 int odevio_profile_read(odevio_plan* plan, float* ms_out);
 
+/* Diagnostic build only (make STAMPS=1 -> libodevio_stamps.so): in-kernel phase totals of the last integrator
+ * launch, in 100 MHz ticks: [0] kernel, [1] waiting in all-gathers, [2] ODEFunc layer products, [3] RNN layer
+ * products, [4] number of all-gathers.  The production library leaves the words at zero. */
+int odevio_debug_stamps(odevio_plan* plan, uint64_t* out8, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libodevio.so")
+LIB_PATH = os.environ.get("ODEVIO_LIB", os.path.join(_HERE, "libodevio.so"))  # ODEVIO_LIB: diagnostic builds
 
 ODEVIO_OK = 0
 ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_MISSING_WEIGHT, ERR_HIP, ERR_NO_DEVICE, ERR_TIMEOUT, ERR_MAX_STEPS = range(-1, -8, -1)
@@ -19,7 +19,7 @@ MODEL_TYPES = {"ode-rnn": 0, "rnn": 1, "cde": 2}
 SYMBOLS = [
     "odevio_version", "odevio_last_error", "odevio_plan_create", "odevio_plan_destroy", "odevio_reserve",
     "odevio_check", "odevio_conv_block_fwd", "odevio_image_encoder_fwd", "odevio_imu_encoder_fwd", "odevio_fuse_fwd", "odevio_ode_func",
-    "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read",
+    "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
 ]
 
 
@@ -59,6 +59,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C odevio_amd/csrc`). The HIP library is the product; there is no CPU fallback.")
+    import torch  # noqa: F401  - load PyTorch's HIP runtime first so that libodevio.so binds to the same libamdhip64
     lib = ctypes.CDLL(LIB_PATH)
     for s in SYMBOLS:
         if not hasattr(lib, s):
@@ -82,6 +83,7 @@ def load():
     lib.odevio_forward.argtypes = [vp, fp, fp, i32, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_profile_enable.argtypes = [vp, i32]
     lib.odevio_profile_read.argtypes = [vp, fp]
+    lib.odevio_debug_stamps.argtypes = [vp, fp, vp]
     for s in SYMBOLS[2:]:
         if s != "odevio_plan_destroy":
             getattr(lib, s).restype = ctypes.c_int

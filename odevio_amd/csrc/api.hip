@@ -359,8 +359,8 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   // ---- exchange buffers + status
   p->xstride = 8 * INTEG_KMAX;
   TRY(dev_alloc(p, (void**)&p->xbuf, (size_t)INTEG_GROUPS * 2 * p->xstride * sizeof(unsigned long long)));
-  TRY(dev_alloc(p, (void**)&p->status, 64));
-  HIPCHK(hipMemsetAsync(p->status, 0, 64, st));
+  TRY(dev_alloc(p, (void**)&p->status, 128));
+  HIPCHK(hipMemsetAsync(p->status, 0, 128, st));
   HIPCHK(hipStreamSynchronize(st));
 #undef TRY
   *out_plan = p;
@@ -561,6 +561,7 @@ static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int su
   a.nsub = is_fixed_step(solver) ? substeps : 0;
   a.atol = c.atol; a.rtol = c.rtol; a.dt0 = c.dt0; a.max_steps = c.max_steps;
   a.xbuf = p->xbuf; a.xstride = p->xstride; a.status = p->status;
+  a.dbg = (unsigned long long*)(p->status + 8);  // 8 x u64 behind the status word (diagnostic build only)
   // LDS carve (floats)
   int maxdim = a.F;
   for (int l = 0; l <= p->nlin; ++l) maxdim = std::max(maxdim, p->dims[l]);
@@ -681,6 +682,13 @@ extern "C" int odevio_profile_read(odevio_plan* p, float* ms_out) {
   ARGCHK(p && ms_out && p->prof, "odevio_profile_read: profiling is not enabled");
   HIPCHK(hipEventSynchronize(p->ev[ODEVIO_N_STAGES]));
   for (int i = 0; i < ODEVIO_N_STAGES; ++i) HIPCHK(hipEventElapsedTime(&ms_out[i], p->ev[i], p->ev[i + 1]));
+  return 0;
+}
+
+extern "C" int odevio_debug_stamps(odevio_plan* p, uint64_t* out8, void* stream) {
+  ARGCHK(p && out8, "odevio_debug_stamps: bad argument");
+  HIPCHK(hipMemcpyAsync(out8, p->status + 8, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 

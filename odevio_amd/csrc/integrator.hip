@@ -38,7 +38,16 @@ typedef unsigned long long u64;
 #define ST_MAX_STEPS (-7)
 #define SPIN_TIMEOUT_TICKS 200000000ull  // 2 s of the 100 MHz s_memrealtime clock
 
+#ifdef ODEVIO_STAMPS
+#define STAMP_NOW() __builtin_amdgcn_s_memrealtime()
+#define STAMP_ADD(acc, t0) (acc) += __builtin_amdgcn_s_memrealtime() - (t0)
+#else
+#define STAMP_NOW() 0ull
+#define STAMP_ADD(acc, t0) (void)(t0)
+#endif
+
 struct Ctx {
+  unsigned long long t_gather, t_layer, t_rnn, n_gather;
   int tid, ks, slot, cu;
   unsigned epoch;
   u64* xb[2];
@@ -53,6 +62,7 @@ __device__ __forceinline__ void put(u64* p, float v, unsigned tag) {
 // Collect n granules of the current exchange into LDS dst[0..n).  Workgroup-uniform result.
 template <int MAXG>
 __device__ __forceinline__ void gather(Ctx& c, int n, float* dst) {
+  const unsigned long long st0 = STAMP_NOW();
   __syncthreads();  // every wave is done reading dst's previous contents
   bool fail = false;
   if (!c.failed) {
@@ -89,6 +99,8 @@ __device__ __forceinline__ void gather(Ctx& c, int n, float* dst) {
     }
   }
   if (__syncthreads_or(fail ? 1 : 0)) c.failed = true;
+  STAMP_ADD(c.t_gather, st0);
+  c.n_gather += 1;
 }
 
 __device__ __forceinline__ float dot4(const f32x4 w, const f32x4 x, float acc) {
@@ -184,6 +196,8 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   c.xb[1] = a.xbuf + (size_t)(2 * g + 1) * a.xstride;
   c.status = a.status;
   c.failed = false;
+  c.t_gather = c.t_layer = c.t_rnn = c.n_gather = 0;
+  const unsigned long long t_begin = STAMP_NOW();
   const int tid = c.tid, ks = c.ks, slot = c.slot, cu = c.cu;
 
   float* xin = smem + a.lds_xin;
@@ -260,10 +274,12 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
       const int K = a.dims[l], N = a.dims[l + 1];
       const int NC = N / INTEG_MEMBERS;
       float acc[2][RT];
+      const unsigned long long sl0 = STAMP_NOW();
       if (a.w_lds_off[l] >= 0)
         layer<RT, true>(wl + a.w_lds_off[l], NC, K, xin, K, 0, xin, K, R, slot, ks, acc);
       else
         layer<RT, false>(a.w[l] + (size_t)cu * NC * K, NC, K, xin, K, 0, xin, K, R, slot, ks, acc);
+      STAMP_ADD(c.t_layer, sl0);
       float v[2];
 #pragma unroll
       for (int ci = 0; ci < 2; ++ci) {
@@ -487,6 +503,7 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
         __syncthreads();
       }
       const float* wsl = a.rw[l] + (size_t)cu * NCV * 2 * F;
+      const unsigned long long sr0 = STAMP_NOW();
       for (int pass = 0; pass * 32 < NCV; ++pass) {
         float acc[2][RT];
         layer<RT, false>(wsl, NCV, F, xin, F, F, hst + (size_t)l * BPG * F, F, BPG, pass * 32 + slot, ks, acc);
@@ -498,6 +515,7 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
           }
         }
       }
+      STAMP_ADD(c.t_rnn, sr0);
       __syncthreads();
       float hn[2] = {0.f, 0.f};
       if (ks < BPG) {
@@ -546,6 +564,17 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
     __syncthreads();
   }
 
+#ifdef ODEVIO_STAMPS
+  if (a.dbg && g == 0 && cu == 0 && tid == 0) {
+    a.dbg[0] = __builtin_amdgcn_s_memrealtime() - t_begin;
+    a.dbg[1] = c.t_gather;
+    a.dbg[2] = c.t_layer;
+    a.dbg[3] = c.t_rnn;
+    a.dbg[4] = c.n_gather;
+  }
+#else
+  (void)t_begin;
+#endif
   // ---- outputs
   if (row_valid && !c.failed) {
 #pragma unroll
