@@ -562,13 +562,18 @@ static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int su
   a.atol = c.atol; a.rtol = c.rtol; a.dt0 = c.dt0; a.max_steps = c.max_steps;
   a.xbuf = p->xbuf; a.xstride = p->xstride; a.status = p->status;
   a.dbg = (unsigned long long*)(p->status + 8);  // 8 x u64 behind the status word (diagnostic build only)
+  {
+    // ODEVIO_SAFE_HANDOFF=1 keeps every group on the placement-independent write-through protocol (tests run both)
+    const char* e = getenv("ODEVIO_SAFE_HANDOFF");
+    a.allow_local = (e && e[0] == '1') ? 0 : 1;
+  }
   // LDS carve (floats)
   int maxdim = a.F;
   for (int l = 0; l <= p->nlin; ++l) maxdim = std::max(maxdim, p->dims[l]);
   int off = 0;
   a.lds_xin = off; off += rt * maxdim;
   a.lds_hst = off; off += rt * a.F;
-  a.lds_misc = off; off += 64 + rt * 32 * 2 + 128 * rt;
+  a.lds_misc = off; off += 64 + rt * 32 * 2 + 128 * rt + INTEG_MAX_LIN * 32;
   off = (off + 3) & ~3;
   a.lds_w = off;
   int budget = (160 * 1024 - 1024) / 4 - off;  // 1 KB left for the kernel's static LDS (__syncthreads_or scratch)

@@ -58,6 +58,7 @@ struct IntegArgs {
   unsigned long long* xbuf;               // [G][2][xstride] 8-byte {tag, value} granules
   int xstride;
   int* status;                            // device status word (0 = ok)
+  int allow_local;                        // 1: groups that prove to sit on one XCD use the L2-local hand-off
   unsigned long long* dbg;                // phase stamps (only written by the ODEVIO_STAMPS diagnostic build)
   // ---- LDS carve (float offsets)
   int lds_xin, lds_hst, lds_misc, lds_w;

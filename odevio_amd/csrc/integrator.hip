@@ -50,13 +50,29 @@ struct Ctx {
   unsigned long long t_gather, t_layer, t_rnn, n_gather;
   int tid, ks, slot, cu;
   unsigned epoch;
-  u64* xb[2];
+  bool local;  // all members of this group share one XCD (verified, not assumed)
+  u64* xb0;  // the two granule buffers of this group; NEVER index them as an array: a runtime index
+  u64* xb1;  // would push Ctx into scratch and turn every poll into a flat_load
   int* status;
   bool failed;
 };
 
-__device__ __forceinline__ void put(u64* p, float v, unsigned tag) {
-  __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), RLX, AGENT);
+// One granule = one naturally aligned 8-byte {tag, value} store: the data is its own flag.
+//  * safe form (any placement): relaxed AGENT-scope store = write-through `sc1`, polled with `sc1` loads;
+//  * local form (only after the group has PROVED at run time that all 32 members sit on one XCD):
+//    a plain store that stays in that XCD's L2, where the members' L1-bypassing polls read it.
+__device__ __forceinline__ void put(u64* p, float v, unsigned tag, bool local) {
+  const u64 g = ((u64)tag << 32) | (u64)__float_as_uint(v);
+  if (local) __hip_atomic_store(p, g, RLX, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, g, RLX, AGENT);
+}
+
+__device__ __forceinline__ u64* cur_buf(const Ctx& c) { return (c.epoch & 1u) ? c.xb1 : c.xb0; }
+
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xfu;
 }
 
 // Collect n granules of the current exchange into LDS dst[0..n).  Workgroup-uniform result.
@@ -66,7 +82,7 @@ __device__ __forceinline__ void gather(Ctx& c, int n, float* dst) {
   __syncthreads();  // every wave is done reading dst's previous contents
   bool fail = false;
   if (!c.failed) {
-    const u64* buf = c.xb[c.epoch & 1];
+    const u64* buf = cur_buf(c);
     u64 g[MAXG];
     unsigned pend = 0;
 #pragma unroll
@@ -111,62 +127,147 @@ __device__ __forceinline__ float dot4(const f32x4 w, const f32x4 x, float acc) {
   return acc;
 }
 
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  return v;
+// ---- transposing reduction over the 16 lanes of a DPP row (one column slot's K-slices) ---------------------
+// Every lane enters with RT partial sums (one per row) and leaves with the TOTAL of row (ks mod RT): at each of
+// the first log2(RT) levels a lane keeps the half of its rows selected by one bit of ks and adds the partner's
+// partials for those rows, so the row index is assembled from the lane's own ks bits and no lane ever holds
+// (or selects from) all rows' totals.  xor-1 / xor-2 partners are DPP quad_perms; the remaining lanes that
+// hold the same row are folded with row_ror (a rotate by 8 then 4 visits lanes i, i+4, i+8, i+12).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int RT>
+__device__ __forceinline__ float reduce_rows(const float (&v)[RT], int ks) {
+  static_assert(RT == 4 || RT == 8, "rows per group");
+  const bool b0 = ks & 1, b1 = ks & 2;
+  float a[RT / 2];
+#pragma unroll
+  for (int i = 0; i < RT / 2; ++i) {
+    const float keep = b0 ? v[2 * i + 1] : v[2 * i];
+    const float send = b0 ? v[2 * i] : v[2 * i + 1];
+    a[i] = keep + dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]: lane ^ 1
+  }
+  float c[RT / 4];
+#pragma unroll
+  for (int i = 0; i < RT / 4; ++i) {
+    const float keep = b1 ? a[2 * i + 1] : a[2 * i];
+    const float send = b1 ? a[2 * i] : a[2 * i + 1];
+    c[i] = keep + dpp_mov<0x4E>(send);  // quad_perm [2,3,0,1]: lane ^ 2
+  }
+  float d;
+  if (RT == 8) {
+    const bool b2 = ks & 4;
+    const float keep = b2 ? c[RT / 4 - 1] : c[0];
+    const float send = b2 ? c[0] : c[RT / 4 - 1];
+    // lane ^ 4 has no DPP form: ds_swizzle bit-mask mode (and 0x1f, or 0, xor 4) - crossbar only, no LDS memory
+    d = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), 0x101F));
+    d += dpp_mov<0x128>(d);  // row_ror:8
+  } else {
+    d = c[0];
+    d += dpp_mov<0x128>(d);  // row_ror:8
+    d += dpp_mov<0x124>(d);  // row_ror:4
+  }
+  return d;
+}
+
+// K-segment of a layer product: nseg chunks of 64 inputs starting at weight chunk jbase, inputs from xs (row
+// stride ld).  Software-pipelined by hand (hipcc issues a load right before its use otherwise, exposing the full
+// L2 / LDS latency every chunk): weight chunks run WD iterations ahead in a register ring, the activations one
+// chunk ahead.  Partial sums are kept as (even k, odd k) pairs so that each multiply-add is one v_pk_fma_f32 on
+// register pairs that the 16-byte loads already deliver adjacent.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define LAYER_WD 4
+
+template <int RT, bool TWO>
+__device__ __forceinline__ void layer_seg(const float* __restrict__ wbase, int NC, int jbase, int nseg,
+                                          const float* xs, int ld, int nr, int c0, int c1, int ks,
+                                          f32x2 (&acc)[2][RT]) {
+  int roff[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) roff[r] = (r < nr ? r : nr - 1) * ld;
+  const float* w0p = wbase + (((size_t)jbase * NC + c0) * 16 + ks) * 4;
+  const float* w1p = wbase + (((size_t)jbase * NC + c1) * 16 + ks) * 4;
+  const size_t wstep = (size_t)NC * 64;
+  xs += 4 * ks;
+  f32x4 wq0[LAYER_WD], wq1[LAYER_WD];
+#pragma unroll
+  for (int d = 0; d < LAYER_WD; ++d) {
+    const int jj = d < nseg ? d : nseg - 1;
+    wq0[d] = *reinterpret_cast<const f32x4*>(w0p + jj * wstep);
+    if (TWO) wq1[d] = *reinterpret_cast<const f32x4*>(w1p + jj * wstep);
+  }
+  f32x4 xc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) xc[r] = *reinterpret_cast<const f32x4*>(xs + roff[r]);
+  for (int j0 = 0; j0 < nseg; j0 += LAYER_WD) {
+#pragma unroll
+    for (int d = 0; d < LAYER_WD; ++d) {
+      const int j = j0 + d;
+      if (j < nseg) {
+        const f32x4 w0 = wq0[d];
+        f32x4 w1 = w0;
+        if (TWO) w1 = wq1[d];
+        const int jn = j + LAYER_WD < nseg ? j + LAYER_WD : nseg - 1;  // refill this ring slot (clamped: harmless re-read)
+        wq0[d] = *reinterpret_cast<const f32x4*>(w0p + jn * wstep);
+        if (TWO) wq1[d] = *reinterpret_cast<const f32x4*>(w1p + jn * wstep);
+        f32x4 xn[RT];
+        const int jx = j + 1 < nseg ? j + 1 : j;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) xn[r] = *reinterpret_cast<const f32x4*>(xs + jx * 64 + roff[r]);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          acc[0][r] = __builtin_elementwise_fma(w0.lo, xc[r].lo, acc[0][r]);
+          acc[0][r] = __builtin_elementwise_fma(w0.hi, xc[r].hi, acc[0][r]);
+          if (TWO) {
+            acc[1][r] = __builtin_elementwise_fma(w1.lo, xc[r].lo, acc[1][r]);
+            acc[1][r] = __builtin_elementwise_fma(w1.hi, xc[r].hi, acc[1][r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) xc[r] = xn[r];
+      }
+    }
+  }
 }
 
 // One layer product for this member: acc[c][r] = sum_k W[col_c][k] * x[r][k], c = 0,1 (local columns
 // col0 = pass*32 + slot and col0 + 16), r < RT.  Inputs k < K1 come from xa, the rest from xb.
-// On return every lane of a 16-lane group holds the full sums.
+// On return res[c] is the total of row (ks mod RT) for column c (reduce_rows).
 template <int RT, bool WLDS>
 __device__ __forceinline__ void layer(const float* __restrict__ wbase, int NC, int K1, const float* xa, int lda,
                                       int K2, const float* xb, int ldb, int nr, int col0, int ks,
-                                      float (&acc)[2][RT]) {
+                                      float (&res)[2]) {
+  f32x2 acc[2][RT];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int r = 0; r < RT; ++r) acc[c][r] = 0.f;
+    for (int r = 0; r < RT; ++r) acc[c][r] = (f32x2){0.f, 0.f};
   const int c0 = col0 < NC ? col0 : NC - 1;  // clamp: out-of-range columns compute garbage that is discarded
   const int c1 = col0 + 16 < NC ? col0 + 16 : c0;
-  const int nj = (K1 + K2) >> 6;
-  const int nj1 = K1 >> 6;
-#pragma unroll 2
-  for (int j = 0; j < nj; ++j) {
-    const float* xs;
-    int ld;
-    if (j < nj1) {
-      xs = xa + j * 64 + 4 * ks;
-      ld = lda;
-    } else {
-      xs = xb + (j - nj1) * 64 + 4 * ks;
-      ld = ldb;
-    }
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wbase + (((size_t)j * NC + c0) * 16 + ks) * 4);
-    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wbase + (((size_t)j * NC + c1) * 16 + ks) * 4);
+  // a wave holds 4 consecutive column slots, so "this wave has a second column" is wave-uniform
+  const bool two = __builtin_amdgcn_readfirstlane((int)(((col0 & ~3) + 16) < NC)) != 0;
+  const int nj1 = K1 >> 6, nj2 = K2 >> 6;
+  if (two) {
+    layer_seg<RT, true>(wbase, NC, 0, nj1, xa, lda, nr, c0, c1, ks, acc);
+    if (nj2) layer_seg<RT, true>(wbase, NC, nj1, nj2, xb, ldb, nr, c0, c1, ks, acc);
+    float s0[RT], s1[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-      const int rr = r < nr ? r : nr - 1;
-      const f32x4 x = *reinterpret_cast<const f32x4*>(xs + rr * ld);
-      acc[0][r] = dot4(w0, x, acc[0][r]);
-      acc[1][r] = dot4(w1, x, acc[1][r]);
+      s0[r] = acc[0][r].x + acc[0][r].y;
+      s1[r] = acc[1][r].x + acc[1][r].y;
     }
+    res[0] = reduce_rows<RT>(s0, ks);
+    res[1] = reduce_rows<RT>(s1, ks);
+  } else {
+    layer_seg<RT, false>(wbase, NC, 0, nj1, xa, lda, nr, c0, c1, ks, acc);
+    if (nj2) layer_seg<RT, false>(wbase, NC, nj1, nj2, xb, ldb, nr, c0, c1, ks, acc);
+    float s0[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) s0[r] = acc[0][r].x + acc[0][r].y;
+    res[0] = reduce_rows<RT>(s0, ks);
+    res[1] = 0.f;
   }
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int r = 0; r < RT; ++r) acc[c][r] = group16_sum(acc[c][r]);
-}
-
-template <int RT>
-__device__ __forceinline__ float pick(const float (&v)[RT], int ks) {
-  float out = v[0];
-#pragma unroll
-  for (int r = 1; r < RT; ++r) out = (ks == r) ? v[r] : out;
-  return out;
 }
 
 __device__ __forceinline__ float hidden_act(float v, int act) {
@@ -192,8 +293,8 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   c.cu = blockIdx.x >> 3;
   if (g >= a.G) return;
   c.epoch = 0;
-  c.xb[0] = a.xbuf + (size_t)(2 * g) * a.xstride;
-  c.xb[1] = a.xbuf + (size_t)(2 * g + 1) * a.xstride;
+  c.xb0 = a.xbuf + (size_t)(2 * g) * a.xstride;
+  c.xb1 = a.xbuf + (size_t)(2 * g + 1) * a.xstride;
   c.status = a.status;
   c.failed = false;
   c.t_gather = c.t_layer = c.t_rnn = c.n_gather = 0;
@@ -207,8 +308,29 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   float* nrm = misc + 64;             // [RT][32]
   float* mv = nrm + RT * 32;          // [RT][32]
   float* pre = mv + RT * 32;          // [4*32][RT]
+  float* bia = pre + 128 * RT;        // [INTEG_MAX_LIN][32] this member's ODEFunc biases
   float* wl = smem + a.lds_w;
 
+  // ---- placement census: the members tell each other their XCD through the SAFE protocol; only if all 32
+  //      agree does the group switch to the L2-local hand-off (a pure speed choice made on observed facts)
+  c.local = false;
+  if (a.allow_local) {
+    ++c.epoch;
+    const unsigned mine = xcc_id();
+    if (tid == 0) put(cur_buf(c) + cu, __uint_as_float(mine + 1u), c.epoch, false);
+    gather<MAXG>(c, INTEG_MEMBERS, nrm);
+    bool same = true;
+    for (int m = 0; m < INTEG_MEMBERS; ++m) same = same && (__float_as_uint(nrm[m]) == mine + 1u);
+    c.local = same && !c.failed;
+    __syncthreads();
+  }
+  if (a.dbg && cu == 0 && tid == 0) reinterpret_cast<unsigned char*>(a.dbg + 5)[g] = c.local ? 1 : 0;  // byte per group
+
+  for (int i = tid; i < a.nlin * 32; i += 256) {
+    const int l = i >> 5, cl = i & 31;
+    const int NC = a.dims[l + 1] / INTEG_MEMBERS;
+    bia[i] = cl < NC ? a.b[l][cu * NC + cl] : 0.f;
+  }
   // ---- resident weight slices -> LDS (read from HBM once per launch)
   for (int l = 0; l < a.nlin; ++l) {
     if (a.w_lds_off[l] < 0) continue;
@@ -264,16 +386,16 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   auto feval = [&](const float (&sv)[2], float (&kout)[2]) {
     ++c.epoch;
     if (has_row) {
-      u64* buf = c.xb[c.epoch & 1];
+      u64* buf = cur_buf(c);
 #pragma unroll
       for (int ci = 0; ci < 2; ++ci)
-        if (colv[ci]) put(buf + ks * F + colg[ci], sv[ci], c.epoch);
+        if (colv[ci]) put(buf + ks * F + colg[ci], sv[ci], c.epoch, c.local);
     }
     gather<MAXG>(c, R * F, xin);
     for (int l = 0; l < a.nlin; ++l) {
       const int K = a.dims[l], N = a.dims[l + 1];
       const int NC = N / INTEG_MEMBERS;
-      float acc[2][RT];
+      float acc[2];
       const unsigned long long sl0 = STAMP_NOW();
       if (a.w_lds_off[l] >= 0)
         layer<RT, true>(wl + a.w_lds_off[l], NC, K, xin, K, 0, xin, K, R, slot, ks, acc);
@@ -283,18 +405,16 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
       float v[2];
 #pragma unroll
       for (int ci = 0; ci < 2; ++ci) {
-        const int cl = ci * 16 + slot;
-        const int cg = cu * NC + (cl < NC ? cl : 0);
-        v[ci] = pick<RT>(acc[ci], ks) + a.b[l][cg];
+        v[ci] = acc[ci] + bia[l * 32 + ci * 16 + slot];
       }
       if (l + 1 < a.nlin) {
         ++c.epoch;
         if (has_row) {
-          u64* buf = c.xb[c.epoch & 1];
+          u64* buf = cur_buf(c);
 #pragma unroll
           for (int ci = 0; ci < 2; ++ci) {
             const int cl = ci * 16 + slot;
-            if (cl < NC) put(buf + ks * N + cu * NC + cl, hidden_act(v[ci], a.act), c.epoch);
+            if (cl < NC) put(buf + ks * N + cu * NC + cl, hidden_act(v[ci], a.act), c.epoch, c.local);
           }
         }
         gather<MAXG>(c, R * N, xin);
@@ -437,7 +557,7 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
           ++c.epoch;
           if (tid < R) {
             const float s = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
-            put(c.xb[c.epoch & 1] + tid * INTEG_MEMBERS + cu, s, c.epoch);
+            put(cur_buf(c) + tid * INTEG_MEMBERS + cu, s, c.epoch, c.local);
           }
           gather<MAXG>(c, R * INTEG_MEMBERS, nrm);
           float tot = 0.f;
@@ -485,10 +605,10 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
     // 1. all-gather the evolved states h~ [R][F] -> hst
     ++c.epoch;
     if (has_row) {
-      u64* buf = c.xb[c.epoch & 1];
+      u64* buf = cur_buf(c);
 #pragma unroll
       for (int ci = 0; ci < 2; ++ci)
-        if (colv[ci]) put(buf + ks * F + colg[ci], y[ci], c.epoch);
+        if (colv[ci]) put(buf + ks * F + colg[ci], y[ci], c.epoch, c.local);
     }
     gather<MAXG>(c, R * F, hst);
     const int NCV = a.rnn_vcols * NCF;
@@ -505,13 +625,13 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
       const float* wsl = a.rw[l] + (size_t)cu * NCV * 2 * F;
       const unsigned long long sr0 = STAMP_NOW();
       for (int pass = 0; pass * 32 < NCV; ++pass) {
-        float acc[2][RT];
+        float acc[2];
         layer<RT, false>(wsl, NCV, F, xin, F, F, hst + (size_t)l * BPG * F, F, BPG, pass * 32 + slot, ks, acc);
         if (ks < BPG) {
 #pragma unroll
           for (int ci = 0; ci < 2; ++ci) {
             const int cl = pass * 32 + ci * 16 + slot;
-            if (cl < NCV) pre[cl * RT + ks] = pick<RT>(acc[ci], ks);
+            if (cl < NCV) pre[cl * RT + ks] = acc[ci];
           }
         }
       }
@@ -545,11 +665,11 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
       if (l + 1 < a.L) {
         ++c.epoch;
         if (ks < BPG) {
-          u64* buf = c.xb[c.epoch & 1];
+          u64* buf = cur_buf(c);
 #pragma unroll
           for (int ci = 0; ci < 2; ++ci) {
             const int ul = ci * 16 + slot;
-            if (ul < NCF) put(buf + ks * F + cu * NCF + ul, hn[ci], c.epoch);
+            if (ul < NCF) put(buf + ks * F + cu * NCF + ul, hn[ci], c.epoch, c.local);
           }
         }
         gather<MAXG>(c, BPG * F, xin);

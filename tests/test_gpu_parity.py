@@ -153,6 +153,20 @@ def test_ode_steps(dev, solver, substeps, rows):
     assert torch.equal(stats[:, 1].cpu().long(), tr["n_accepted"])
 
 
+def test_safe_and_local_handoff_agree(dev, monkeypatch):
+    """The placement-independent write-through hand-off and the verified same-XCD one give the same bits."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="dopri5")
+    model, _ = make_model(opt, seed=34)
+    y0, t0, t1 = _rows_problem(32, seed=7)
+    monkeypatch.setenv("ODEVIO_SAFE_HANDOFF", "1")
+    a, sa = model.ode_steps(y0.cuda(), t0.cuda(), t1.cuda(), return_stats=True)
+    model.check()
+    monkeypatch.setenv("ODEVIO_SAFE_HANDOFF", "0")
+    b, sb = model.ode_steps(y0.cuda(), t0.cuda(), t1.cuda(), return_stats=True)
+    model.check()
+    assert torch.equal(a, b) and torch.equal(sa, sb)
+
+
 def test_euler_reference_semantics(dev):
     # torchode's controller never changes dt without an error estimate: 1e-4 steps to the end
     opt = default_opt(img_h=64, img_w=128, ode_solver="euler")
