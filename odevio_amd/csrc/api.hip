@@ -358,7 +358,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   }
   // ---- exchange buffers + status
   p->xstride = 8 * INTEG_KMAX;
-  TRY(dev_alloc(p, (void**)&p->xbuf, (size_t)INTEG_GROUPS * 2 * p->xstride * sizeof(unsigned long long)));
+  TRY(dev_alloc(p, (void**)&p->xbuf, (size_t)INTEG_GROUPS * INTEG_HALVES * 2 * p->xstride * sizeof(unsigned long long)));
   TRY(dev_alloc(p, (void**)&p->status, 128));
   HIPCHK(hipMemsetAsync(p->status, 0, 128, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -570,11 +570,15 @@ static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int su
   // LDS carve (floats)
   int maxdim = a.F;
   for (int l = 0; l <= p->nlin; ++l) maxdim = std::max(maxdim, p->dims[l]);
-  int off = 0;
-  a.lds_xin = off; off += rt * maxdim;
-  a.lds_hst = off; off += rt * a.F;
-  a.lds_misc = off; off += 64 + rt * 32 * 2 + 128 * rt + INTEG_MAX_LIN * 32;
-  off = (off + 3) & ~3;
+  // per-half block: xin [rt][maxdim] | hst [rt][F] | misc (red 64, nrm rt*32, mv rt*32, pre 128*rt)
+  int hoff = rt * maxdim;
+  a.lds_hst = hoff; hoff += rt * a.F;
+  a.lds_misc = hoff; hoff += 64 + rt * 32 * 2 + 128 * rt;
+  hoff = (hoff + 3) & ~3;
+  a.lds_half0 = 0;
+  a.lds_half_stride = hoff;
+  int off = INTEG_HALVES * hoff;
+  a.lds_bias = off; off += INTEG_MAX_LIN * 32;
   a.lds_w = off;
   int budget = (160 * 1024 - 1024) / 4 - off;  // 1 KB left for the kernel's static LDS (__syncthreads_or scratch)
   // keep the largest slices that fit resident; the rest stream from L2
@@ -595,7 +599,7 @@ static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int su
 static int launch_integ(odevio_plan* p, IntegArgs& a, int rt, size_t lds, hipStream_t st) {
   if (p->n_cu < INTEG_GROUPS * INTEG_MEMBERS)
     return fail(ODEVIO_ERR_UNSUPPORTED, "persistent integrator needs %d CUs, device has %d", INTEG_GROUPS * INTEG_MEMBERS, p->n_cu);
-  HIPCHK(hipMemsetAsync(p->xbuf, 0, (size_t)INTEG_GROUPS * 2 * p->xstride * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(p->xbuf, 0, (size_t)INTEG_GROUPS * INTEG_HALVES * 2 * p->xstride * sizeof(unsigned long long), st));
   const int e = launch_integrator(a, rt, lds, st);
   if (e != 0) return fail(ODEVIO_ERR_HIP, "integrator launch failed: %s (lds %zu B)", hipGetErrorString((hipError_t)e), lds);
   return 0;
@@ -604,20 +608,21 @@ static int launch_integ(odevio_plan* p, IntegArgs& a, int rt, size_t lds, hipStr
 static int run_sequence(odevio_plan* p, const float* fused, const float* ts, const float* hc, int B, int P,
                         float* out_seq, float* hT, int32_t* stats, hipStream_t st) {
   const int L = p->cfg.rnn_num_layers;
-  const int bpg_max = 8 / L;  // rows per group <= 8
-  const int chunk = INTEG_GROUPS * bpg_max;
+  const int bph_max = 8 / L;  // rows per half <= 8
+  const int slots = INTEG_GROUPS * INTEG_HALVES;
+  const int chunk = slots * bph_max;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = std::min(chunk, B - b0);
-    const int BPG = (nb + INTEG_GROUPS - 1) / INTEG_GROUPS;
-    const int R = L * BPG;
-    const int rt = R <= 4 ? 4 : 8;
+    const int BPH = (nb + slots - 1) / slots;
+    const int R = L * BPH;
+    const int rt = R <= 2 ? 2 : (R <= 4 ? 4 : 8);
     IntegArgs a;
     size_t lds;
     int rc = integ_common(p, a, rt, p->cfg.ode_solver, p->cfg.ode_substeps, &lds);
     if (rc) return rc;
     a.mode = p->cfg.model_type == ODEVIO_MODEL_RNN ? MODE_RNN_ONLY : MODE_ODE_RNN;
     a.B = B; a.P = P; a.b_begin = b0; a.b_end = b0 + nb;
-    a.BPG = BPG; a.G = (nb + BPG - 1) / BPG; a.rows_per_group = R;
+    a.BPH = BPH; a.G = (nb + INTEG_HALVES * BPH - 1) / (INTEG_HALVES * BPH); a.rows_per_half = R;
     a.fused = fused; a.ts = ts; a.ts_relative = hc ? 0 : 1; a.hc = hc; a.out_seq = out_seq; a.hT = hT; a.stats = stats;
     if ((rc = launch_integ(p, a, rt, lds, st))) return rc;
   }
@@ -627,18 +632,19 @@ static int run_sequence(odevio_plan* p, const float* fused, const float* ts, con
 static int run_rows(odevio_plan* p, int mode, const float* y, const float* t0, const float* t1, int rows, int solver,
                     int substeps, float* y_out, int32_t* stats, hipStream_t st) {
   if (p->cfg.model_type != ODEVIO_MODEL_ODE_RNN) return fail(ODEVIO_ERR_UNSUPPORTED, "plan has no ODEFunc");
-  const int chunk = INTEG_GROUPS * 8;
+  const int slots = INTEG_GROUPS * INTEG_HALVES;
+  const int chunk = slots * 8;
   for (int r0 = 0; r0 < rows; r0 += chunk) {
     const int nr = std::min(chunk, rows - r0);
-    const int BPG = (nr + INTEG_GROUPS - 1) / INTEG_GROUPS;
-    const int rt = BPG <= 4 ? 4 : 8;
+    const int BPH = (nr + slots - 1) / slots;
+    const int rt = BPH <= 2 ? 2 : (BPH <= 4 ? 4 : 8);
     IntegArgs a;
     size_t lds;
     int rc = integ_common(p, a, rt, solver, substeps, &lds);
     if (rc) return rc;
     a.mode = mode;
     a.B = rows; a.P = 1; a.b_begin = r0; a.b_end = r0 + nr;
-    a.BPG = BPG; a.G = (nr + BPG - 1) / BPG; a.rows_per_group = BPG;
+    a.BPH = BPH; a.G = (nr + INTEG_HALVES * BPH - 1) / (INTEG_HALVES * BPH); a.rows_per_half = BPH;
     a.y0 = y; a.t0 = t0; a.t1 = t1; a.y_out = y_out; a.stats = stats;
     if ((rc = launch_integ(p, a, rt, lds, st))) return rc;
   }

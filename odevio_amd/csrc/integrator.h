@@ -6,6 +6,7 @@
 #define INTEG_MAX_L 4      // RNN layers
 #define INTEG_MEMBERS 32   // workgroups (CUs) per row group = one XCD under round-robin dispatch
 #define INTEG_GROUPS 8
+#define INTEG_HALVES 2     // independent row sets a workgroup alternates between (latency hiding)
 #define INTEG_KMAX 1024    // widest vector exchanged between layers
 
 enum IntegMode { MODE_ODE_RNN = 0, MODE_RNN_ONLY = 1, MODE_ODE_STEPS = 2, MODE_FEVAL = 3 };
@@ -41,8 +42,8 @@ struct IntegArgs {
   int mode;
   int B, P;                               // batch (tensor stride), intervals (timestamps per row = P + 1)
   int b_begin, b_end;                     // batch elements (sequence modes) or rows (row modes) of THIS launch
-  int G, BPG;                             // active groups, batch elements (or rows) per group
-  int rows_per_group;                     // L*BPG (sequence modes) or BPG (row modes)
+  int G, BPH;                             // active groups; sequences (sequence modes) or rows (row modes) per HALF
+  int rows_per_half;                      // L*BPH (sequence modes) or BPH (row modes)
   const float* fused;                     // [B][P][F]
   const float* ts;                        // [B][P+1]
   int ts_relative;                        // 1: subtract ts[:,0] (hc == NULL), reference PoseODERNN.py:100
@@ -55,13 +56,14 @@ struct IntegArgs {
   float* y_out;                           // [rows][F]
   int* stats;                             // [rows][2] or null
   // ---- infrastructure
-  unsigned long long* xbuf;               // [G][2][xstride] 8-byte {tag, value} granules
+  unsigned long long* xbuf;               // [G][halves][2][xstride] 8-byte {tag, value} granules
   int xstride;
   int* status;                            // device status word (0 = ok)
   int allow_local;                        // 1: groups that prove to sit on one XCD use the L2-local hand-off
   unsigned long long* dbg;                // phase stamps (only written by the ODEVIO_STAMPS diagnostic build)
   // ---- LDS carve (float offsets)
-  int lds_xin, lds_hst, lds_misc, lds_w;
+  int lds_half0, lds_half_stride;         // per-half block: xin at +0, hst at +lds_hst, misc at +lds_misc
+  int lds_hst, lds_misc, lds_bias, lds_w;
 };
 
 int launch_integrator(const IntegArgs& a, int rt, size_t lds_bytes, void* stream);

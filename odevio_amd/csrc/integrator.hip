@@ -51,8 +51,6 @@ struct Ctx {
   int tid, ks, slot, cu;
   unsigned epoch;
   bool local;  // all members of this group share one XCD (verified, not assumed)
-  u64* xb0;  // the two granule buffers of this group; NEVER index them as an array: a runtime index
-  u64* xb1;  // would push Ctx into scratch and turn every poll into a flat_load
   int* status;
   bool failed;
 };
@@ -67,8 +65,6 @@ __device__ __forceinline__ void put(u64* p, float v, unsigned tag, bool local) {
   else __hip_atomic_store(p, g, RLX, AGENT);
 }
 
-__device__ __forceinline__ u64* cur_buf(const Ctx& c) { return (c.epoch & 1u) ? c.xb1 : c.xb0; }
-
 __device__ __forceinline__ unsigned xcc_id() {
   unsigned v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -77,12 +73,11 @@ __device__ __forceinline__ unsigned xcc_id() {
 
 // Collect n granules of the current exchange into LDS dst[0..n).  Workgroup-uniform result.
 template <int MAXG>
-__device__ __forceinline__ void gather(Ctx& c, int n, float* dst) {
+__device__ __forceinline__ void gather(Ctx& c, const u64* buf, unsigned tag, int n, float* dst) {
   const unsigned long long st0 = STAMP_NOW();
   __syncthreads();  // every wave is done reading dst's previous contents
   bool fail = false;
   if (!c.failed) {
-    const u64* buf = cur_buf(c);
     u64 g[MAXG];
     unsigned pend = 0;
 #pragma unroll
@@ -96,7 +91,7 @@ __device__ __forceinline__ void gather(Ctx& c, int n, float* dst) {
         if ((pend >> j) & 1u) g[j] = __hip_atomic_load(buf + c.tid + 256 * j, RLX, AGENT);
 #pragma unroll
       for (int j = 0; j < MAXG; ++j)
-        if (((pend >> j) & 1u) && (unsigned)(g[j] >> 32) == c.epoch) {
+        if (((pend >> j) & 1u) && (unsigned)(g[j] >> 32) == tag) {
           dst[c.tid + 256 * j] = __uint_as_float((unsigned)g[j]);
           pend &= ~(1u << j);
         }
@@ -139,8 +134,8 @@ __device__ __forceinline__ float dpp_mov(float v) {
 }
 template <int RT>
 __device__ __forceinline__ float reduce_rows(const float (&v)[RT], int ks) {
-  static_assert(RT == 4 || RT == 8, "rows per group");
-  const bool b0 = ks & 1, b1 = ks & 2;
+  static_assert(RT == 2 || RT == 4 || RT == 8, "rows per half");
+  const bool b0 = ks & 1, b1 = ks & 2, b2 = ks & 4;
   float a[RT / 2];
 #pragma unroll
   for (int i = 0; i < RT / 2; ++i) {
@@ -148,25 +143,31 @@ __device__ __forceinline__ float reduce_rows(const float (&v)[RT], int ks) {
     const float send = b0 ? v[2 * i] : v[2 * i + 1];
     a[i] = keep + dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]: lane ^ 1
   }
-  float c[RT / 4];
-#pragma unroll
-  for (int i = 0; i < RT / 4; ++i) {
-    const float keep = b1 ? a[2 * i + 1] : a[2 * i];
-    const float send = b1 ? a[2 * i] : a[2 * i + 1];
-    c[i] = keep + dpp_mov<0x4E>(send);  // quad_perm [2,3,0,1]: lane ^ 2
-  }
   float d;
-  if (RT == 8) {
-    const bool b2 = ks & 4;
-    const float keep = b2 ? c[RT / 4 - 1] : c[0];
-    const float send = b2 ? c[0] : c[RT / 4 - 1];
-    // lane ^ 4 has no DPP form: ds_swizzle bit-mask mode (and 0x1f, or 0, xor 4) - crossbar only, no LDS memory
-    d = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), 0x101F));
-    d += dpp_mov<0x128>(d);  // row_ror:8
+  if (RT == 2) {
+    d = a[0];
+    d += dpp_mov<0x4E>(d);  // lanes with the same ks&1: ^2, then +8, +4
+    d += dpp_mov<0x128>(d);
+    d += dpp_mov<0x124>(d);
   } else {
-    d = c[0];
-    d += dpp_mov<0x128>(d);  // row_ror:8
-    d += dpp_mov<0x124>(d);  // row_ror:4
+    float c[RT / 4 > 0 ? RT / 4 : 1];
+#pragma unroll
+    for (int i = 0; i < RT / 4; ++i) {
+      const float keep = b1 ? a[2 * i + 1] : a[2 * i];
+      const float send = b1 ? a[2 * i] : a[2 * i + 1];
+      c[i] = keep + dpp_mov<0x4E>(send);  // quad_perm [2,3,0,1]: lane ^ 2
+    }
+    if (RT == 8) {
+      const float keep = b2 ? c[RT / 4 - 1] : c[0];
+      const float send = b2 ? c[0] : c[RT / 4 - 1];
+      // lane ^ 4 has no DPP form: ds_swizzle bit-mask mode (and 0x1f, or 0, xor 4) - crossbar only, no LDS memory
+      d = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), 0x101F));
+      d += dpp_mov<0x128>(d);  // row_ror:8
+    } else {
+      d = c[0];
+      d += dpp_mov<0x128>(d);  // row_ror:8
+      d += dpp_mov<0x124>(d);  // row_ror:4
+    }
   }
   return d;
 }
@@ -281,10 +282,39 @@ __device__ __forceinline__ float hidden_act(float v, int act) {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+
+// ================================================================================================
+// The kernel.  Each workgroup serves INTEG_HALVES independent row sets ("halves") of its group in
+// strict alternation: while half A's activations are in flight to the other members, the workgroup
+// computes half B's layer, so the hand-off latency of one half hides under the arithmetic of the
+// other.  The halves never exchange data (rows are independent), own separate granule buffers and
+// advance through the same sequence of exchanges, so one epoch counter serves both.
+// ================================================================================================
+template <int RT>
+struct Half {
+  u64* xb;   // granule buffers: parity 0 at xb, parity 1 at xb + xstride.  Keep ONE pointer: LLVM turns a select
+  int xstride;  // between two adjacent pointer fields into a runtime-indexed load, which pushes the whole struct
+                // to scratch (and every poll becomes a flat_load).
+  float *xin, *hst, *red, *nrm, *mv, *pre;
+  bool active;     // this half has at least one real row (workgroup-uniform)
+  bool has_row;    // this thread's ks addresses a row slot of the half
+  bool row_valid;  // ... and that slot holds a real sequence / row
+  int row_l, row_b, grow;
+  float y[2];
+  float k[7][2];
+  float t, t1, dt, dtn;
+  bool last, running;
+  int sub_left, n_steps, n_acc;
+};
+
+template <int RT>
+__device__ __forceinline__ u64* buf_of(const Half<RT>& h, unsigned epoch) { return h.xb + ((epoch & 1u) ? h.xstride : 0); }
+
 template <int RT>
 __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int MAXG = RT * (INTEG_KMAX / 256);
+  constexpr int MAXG = (RT * INTEG_KMAX + 255) / 256;
+  constexpr int NH = INTEG_HALVES;
   Ctx c;
   c.tid = threadIdx.x;
   c.ks = c.tid & 15;
@@ -293,34 +323,85 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   c.cu = blockIdx.x >> 3;
   if (g >= a.G) return;
   c.epoch = 0;
-  c.xb0 = a.xbuf + (size_t)(2 * g) * a.xstride;
-  c.xb1 = a.xbuf + (size_t)(2 * g + 1) * a.xstride;
   c.status = a.status;
   c.failed = false;
+  c.local = false;
   c.t_gather = c.t_layer = c.t_rnn = c.n_gather = 0;
   const unsigned long long t_begin = STAMP_NOW();
   const int tid = c.tid, ks = c.ks, slot = c.slot, cu = c.cu;
 
-  float* xin = smem + a.lds_xin;
-  float* hst = smem + a.lds_hst;
-  float* misc = smem + a.lds_misc;
-  float* red = misc;                  // [4][16]
-  float* nrm = misc + 64;             // [RT][32]
-  float* mv = nrm + RT * 32;          // [RT][32]
-  float* pre = mv + RT * 32;          // [4*32][RT]
-  float* bia = pre + 128 * RT;        // [INTEG_MAX_LIN][32] this member's ODEFunc biases
+  const bool seq_mode = (a.mode == MODE_ODE_RNN || a.mode == MODE_RNN_ONLY);
+  const int F = a.F;
+  const int NCF = F / INTEG_MEMBERS;
+  const int R = a.rows_per_half;
+  const int BPH = a.BPH;
+  float* bia = smem + a.lds_bias;  // [INTEG_MAX_LIN][32] this member's ODEFunc biases
   float* wl = smem + a.lds_w;
+
+  Half<RT> hs[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    Half<RT>& H = hs[h];
+    H.xb = a.xbuf + (size_t)((g * NH + h) * 2) * a.xstride;
+    H.xstride = a.xstride;
+    float* base = smem + a.lds_half0 + h * a.lds_half_stride;
+    H.xin = base;
+    H.hst = base + a.lds_hst;
+    H.red = base + a.lds_misc;     // [4][16]
+    H.nrm = H.red + 64;            // [RT][32]
+    H.mv = H.nrm + RT * 32;        // [RT][32]
+    H.pre = H.mv + RT * 32;        // [4*32][RT]
+    const int first = a.b_begin + (g * NH + h) * BPH;  // first sequence (or row) of this half
+    H.active = first < a.b_end;
+    H.has_row = ks < R;
+    H.row_l = 0;
+    H.row_b = 0;
+    H.grow = 0;
+    H.row_valid = false;
+    if (H.has_row) {
+      if (seq_mode) {
+        H.row_l = ks / BPH;
+        H.row_b = first + (ks - H.row_l * BPH);
+        H.row_valid = H.row_b < a.b_end;
+        H.grow = H.row_l * a.B + H.row_b;
+      } else {
+        H.grow = first + ks;
+        H.row_valid = H.grow < a.b_end;
+      }
+    }
+    H.y[0] = H.y[1] = 0.f;
+    H.n_steps = H.n_acc = 0;
+  }
+
+  // this thread's columns of an F-wide vector
+  int colg[2];
+  bool colv[2];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int cl = ci * 16 + slot;
+    colv[ci] = cl < NCF;
+    colg[ci] = cu * NCF + (colv[ci] ? cl : 0);
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    if (!hs[h].row_valid) continue;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      if (!colv[ci]) continue;
+      if (seq_mode) hs[h].y[ci] = a.hc ? a.hc[(size_t)hs[h].grow * F + colg[ci]] : 0.f;
+      else hs[h].y[ci] = a.y0[(size_t)hs[h].grow * F + colg[ci]];
+    }
+  }
 
   // ---- placement census: the members tell each other their XCD through the SAFE protocol; only if all 32
   //      agree does the group switch to the L2-local hand-off (a pure speed choice made on observed facts)
-  c.local = false;
   if (a.allow_local) {
     ++c.epoch;
     const unsigned mine = xcc_id();
-    if (tid == 0) put(cur_buf(c) + cu, __uint_as_float(mine + 1u), c.epoch, false);
-    gather<MAXG>(c, INTEG_MEMBERS, nrm);
+    if (tid == 0) put(buf_of(hs[0], c.epoch) + cu, __uint_as_float(mine + 1u), c.epoch, false);
+    gather<MAXG>(c, buf_of(hs[0], c.epoch), c.epoch, INTEG_MEMBERS, hs[0].nrm);
     bool same = true;
-    for (int m = 0; m < INTEG_MEMBERS; ++m) same = same && (__float_as_uint(nrm[m]) == mine + 1u);
+    for (int m = 0; m < INTEG_MEMBERS; ++m) same = same && (__float_as_uint(hs[0].nrm[m]) == mine + 1u);
     c.local = same && !c.failed;
     __syncthreads();
   }
@@ -342,96 +423,68 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   }
   __syncthreads();
 
-  const bool seq_mode = (a.mode == MODE_ODE_RNN || a.mode == MODE_RNN_ONLY);
-  const int F = a.F;
-  const int NCF = F / INTEG_MEMBERS;
-  const int R = a.rows_per_group;
-  const int BPG = a.BPG;
-  // this thread's row
-  const bool has_row = ks < R;
-  int row_l = 0, row_b = 0, grow = 0;  // layer, batch index, global row id
-  bool row_valid = false;
-  if (has_row) {
-    if (seq_mode) {
-      row_l = ks / BPG;
-      row_b = a.b_begin + g * BPG + (ks - row_l * BPG);
-      row_valid = row_b < a.b_end;
-      grow = row_l * a.B + row_b;
-    } else {
-      grow = a.b_begin + g * BPG + ks;
-      row_valid = grow < a.b_end;
-    }
-  }
-  // this thread's columns of an F-wide vector
-  int colg[2];
-  bool colv[2];
-#pragma unroll
-  for (int ci = 0; ci < 2; ++ci) {
-    const int cl = ci * 16 + slot;
-    colv[ci] = cl < NCF;
-    colg[ci] = cu * NCF + (colv[ci] ? cl : 0);
-  }
-
-  float y[2] = {0.f, 0.f};
-  if (row_valid) {
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-      if (!colv[ci]) continue;
-      if (seq_mode) y[ci] = a.hc ? a.hc[(size_t)grow * F + colg[ci]] : 0.f;
-      else y[ci] = a.y0[(size_t)grow * F + colg[ci]];
-    }
-  }
-
-  // vector field: stage values sv (this thread's elements) -> kout
-  auto feval = [&](const float (&sv)[2], float (&kout)[2]) {
+  // vector field for both halves: stage values sv[h] (this thread's elements) -> ko[h]
+  auto feval = [&](const float (&sv)[NH][2], float (&ko)[NH][2]) {
     ++c.epoch;
-    if (has_row) {
-      u64* buf = cur_buf(c);
 #pragma unroll
-      for (int ci = 0; ci < 2; ++ci)
-        if (colv[ci]) put(buf + ks * F + colg[ci], sv[ci], c.epoch, c.local);
+    for (int h = 0; h < NH; ++h) {
+      if (hs[h].active && hs[h].has_row) {
+        u64* buf = buf_of(hs[h], c.epoch);
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+          if (colv[ci]) put(buf + ks * F + colg[ci], sv[h][ci], c.epoch, c.local);
+      }
     }
-    gather<MAXG>(c, R * F, xin);
     for (int l = 0; l < a.nlin; ++l) {
       const int K = a.dims[l], N = a.dims[l + 1];
       const int NC = N / INTEG_MEMBERS;
-      float acc[2];
-      const unsigned long long sl0 = STAMP_NOW();
-      if (a.w_lds_off[l] >= 0)
-        layer<RT, true>(wl + a.w_lds_off[l], NC, K, xin, K, 0, xin, K, R, slot, ks, acc);
-      else
-        layer<RT, false>(a.w[l] + (size_t)cu * NC * K, NC, K, xin, K, 0, xin, K, R, slot, ks, acc);
-      STAMP_ADD(c.t_layer, sl0);
-      float v[2];
+      const bool more = l + 1 < a.nlin;
 #pragma unroll
-      for (int ci = 0; ci < 2; ++ci) {
-        v[ci] = acc[ci] + bia[l * 32 + ci * 16 + slot];
-      }
-      if (l + 1 < a.nlin) {
-        ++c.epoch;
-        if (has_row) {
-          u64* buf = cur_buf(c);
+      for (int h = 0; h < NH; ++h) {
+        if (!hs[h].active) continue;
+        gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, R * K, hs[h].xin);
+        float res[2];
+        const unsigned long long sl0 = STAMP_NOW();
+        if (a.w_lds_off[l] >= 0)
+          layer<RT, true>(wl + a.w_lds_off[l], NC, K, hs[h].xin, K, 0, hs[h].xin, K, R, slot, ks, res);
+        else
+          layer<RT, false>(a.w[l] + (size_t)cu * NC * K, NC, K, hs[h].xin, K, 0, hs[h].xin, K, R, slot, ks, res);
+        STAMP_ADD(c.t_layer, sl0);
+        float v[2];
 #pragma unroll
-          for (int ci = 0; ci < 2; ++ci) {
-            const int cl = ci * 16 + slot;
-            if (cl < NC) put(buf + ks * N + cu * NC + cl, hidden_act(v[ci], a.act), c.epoch, c.local);
+        for (int ci = 0; ci < 2; ++ci) v[ci] = res[ci] + bia[l * 32 + ci * 16 + slot];
+        if (more) {
+          if (hs[h].has_row) {
+            u64* buf = buf_of(hs[h], c.epoch + 1);
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+              const int cl = ci * 16 + slot;
+              if (cl < NC) put(buf + ks * N + cu * NC + cl, hidden_act(v[ci], a.act), c.epoch + 1, c.local);
+            }
           }
+        } else {
+          ko[h][0] = tanhf(v[0]);
+          ko[h][1] = tanhf(v[1]);
         }
-        gather<MAXG>(c, R * N, xin);
-      } else {
-        kout[0] = tanhf(v[0]);
-        kout[1] = tanhf(v[1]);
       }
+      if (more) ++c.epoch;
     }
   };
 
   if (a.mode == MODE_FEVAL) {
-    float kk[2];
-    feval(y, kk);
-    if (row_valid) {
+    float sv[NH][2], kk[NH][2] = {};
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      sv[h][0] = hs[h].y[0];
+      sv[h][1] = hs[h].y[1];
+    }
+    feval(sv, kk);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      if (!hs[h].row_valid) continue;
 #pragma unroll
       for (int ci = 0; ci < 2; ++ci)
-        if (colv[ci]) a.y_out[(size_t)grow * F + colg[ci]] = kk[ci];
+        if (colv[ci]) a.y_out[(size_t)hs[h].grow * F + colg[ci]] = kk[h][ci];
     }
     return;
   }
@@ -439,80 +492,94 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   const int S = a.tab.stages;
   const float inv_order = -1.f / (float)a.tab.order;
   const int n_int = seq_mode ? a.P : 1;
-  int n_steps = 0, n_acc = 0;
+  const bool fixed = (a.tab.has_err == 0 && a.nsub > 0);
 
   for (int it = 0; it < n_int && !c.failed; ++it) {
     // ======================= ODE phase =======================
     if (a.mode != MODE_RNN_ONLY) {
-      float t = 0.f, t1 = 0.f;
-      if (row_valid) {
-        if (seq_mode) {
-          const float* tr = a.ts + (size_t)row_b * (a.P + 1);
-          const float base = a.ts_relative ? tr[0] : 0.f;
-          t = tr[it] - base;
-          t1 = tr[it + 1] - base;
-        } else {
-          t = a.t0[grow];
-          t1 = a.t1[grow];
-        }
-      }
-      const bool fixed = (a.tab.has_err == 0 && a.nsub > 0);
-      float dt, dtn = a.dt0;
-      bool last = false, running;
-      int sub_left = a.nsub;
-      if (fixed) {
-        dt = (t1 - t) / (float)a.nsub;
-        running = row_valid;
-      } else {
-        const float span = t1 - t;
-        last = dtn >= span;
-        dt = last ? span : dtn;
-        running = row_valid && (t < t1);
-      }
-      float k[7][2];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) k[j][0] = k[j][1] = 0.f;
+      for (int h = 0; h < NH; ++h) {
+        Half<RT>& H = hs[h];
+        H.t = 0.f;
+        H.t1 = 0.f;
+        if (H.row_valid) {
+          if (seq_mode) {
+            const float* tr = a.ts + (size_t)H.row_b * (a.P + 1);
+            const float base = a.ts_relative ? tr[0] : 0.f;
+            H.t = tr[it] - base;
+            H.t1 = tr[it + 1] - base;
+          } else {
+            H.t = a.t0[H.grow];
+            H.t1 = a.t1[H.grow];
+          }
+        }
+        H.dtn = a.dt0;
+        H.last = false;
+        H.sub_left = a.nsub;
+        if (fixed) {
+          H.dt = (H.t1 - H.t) / (float)a.nsub;
+          H.running = H.row_valid;
+        } else {
+          const float span = H.t1 - H.t;
+          H.last = H.dtn >= span;
+          H.dt = H.last ? span : H.dtn;
+          H.running = H.row_valid && (H.t < H.t1);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) H.k[j][0] = H.k[j][1] = 0.f;
+      }
       bool have_k1 = false;
       int guard = 0;
-      while (__syncthreads_or((running && has_row) ? 1 : 0)) {
+      while (__syncthreads_or(((hs[0].running && hs[0].has_row) || (hs[NH - 1].running && hs[NH - 1].has_row)) ? 1 : 0)) {
         if (c.failed) break;
         if (++guard > a.max_steps) {
           if (tid == 0) atomicCAS(c.status, 0, ST_MAX_STEPS);
           break;
         }
-        float sv[2] = {y[0], y[1]};
+        float sv[NH][2];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          sv[h][0] = hs[h].y[0];
+          sv[h][1] = hs[h].y[1];
+        }
         for (int s = 0; s < S; ++s) {
           if (s == 0 && have_k1) continue;
           if (s > 0) {
-            float a0 = 0.f, a1 = 0.f;
-            bool first = true;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-              if (j < s) {
-                const float co = a.tab.a[s][j];
-                if (co != 0.f) {
-                  // same association as the oracle: acc = k_j*a_sj summed left to right
-                  a0 = first ? k[j][0] * co : a0 + k[j][0] * co;
-                  a1 = first ? k[j][1] * co : a1 + k[j][1] * co;
-                  first = false;
+            for (int h = 0; h < NH; ++h) {
+              float a0 = 0.f, a1 = 0.f;
+              bool first = true;
+#pragma unroll
+              for (int j = 0; j < 6; ++j) {
+                if (j < s) {
+                  const float co = a.tab.a[s][j];
+                  if (co != 0.f) {
+                    // same association as the oracle: acc = k_j*a_sj summed left to right
+                    a0 = first ? hs[h].k[j][0] * co : a0 + hs[h].k[j][0] * co;
+                    a1 = first ? hs[h].k[j][1] * co : a1 + hs[h].k[j][1] * co;
+                    first = false;
+                  }
                 }
               }
+              sv[h][0] = hs[h].y[0] + hs[h].dt * a0;
+              sv[h][1] = hs[h].y[1] + hs[h].dt * a1;
             }
-            sv[0] = y[0] + dt * a0;
-            sv[1] = y[1] + dt * a1;
           }
-          float ko[2];
+          float ko[NH][2] = {};
           feval(sv, ko);
 #pragma unroll
-          for (int j = 0; j < 7; ++j)
-            if (j == s) {
-              k[j][0] = ko[0];
-              k[j][1] = ko[1];
-            }
+          for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+              if (j == s) {
+                hs[h].k[j][0] = ko[h][0];
+                hs[h].k[j][1] = ko[h][1];
+              }
         }
         // y1 = y + dt * sum b_j k_j   (FSAL: b_last = 0 and the sum equals the last stage's argument)
-        float y1[2], er[2];
-        {
+        float y1[NH][2], er[NH][2];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
           float s0 = 0.f, s1 = 0.f, e0 = 0.f, e1 = 0.f;
           bool fb = true, fe = true;
 #pragma unroll
@@ -520,80 +587,98 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
             if (j < S) {
               const float bj = a.tab.b[j];
               if (bj != 0.f) {
-                s0 = fb ? k[j][0] * bj : s0 + k[j][0] * bj;
-                s1 = fb ? k[j][1] * bj : s1 + k[j][1] * bj;
+                s0 = fb ? hs[h].k[j][0] * bj : s0 + hs[h].k[j][0] * bj;
+                s1 = fb ? hs[h].k[j][1] * bj : s1 + hs[h].k[j][1] * bj;
                 fb = false;
               }
               const float ej = a.tab.e[j];
               if (a.tab.has_err && ej != 0.f) {
-                e0 = fe ? k[j][0] * ej : e0 + k[j][0] * ej;
-                e1 = fe ? k[j][1] * ej : e1 + k[j][1] * ej;
+                e0 = fe ? hs[h].k[j][0] * ej : e0 + hs[h].k[j][0] * ej;
+                e1 = fe ? hs[h].k[j][1] * ej : e1 + hs[h].k[j][1] * ej;
                 fe = false;
               }
             }
           }
-          y1[0] = y[0] + dt * s0;
-          y1[1] = y[1] + dt * s1;
-          er[0] = dt * e0;
-          er[1] = dt * e1;
+          y1[h][0] = hs[h].y[0] + hs[h].dt * s0;
+          y1[h][1] = hs[h].y[1] + hs[h].dt * s1;
+          er[h][0] = hs[h].dt * e0;
+          er[h][1] = hs[h].dt * e1;
         }
-        bool accept = true;
+        bool accept[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) accept[h] = true;
         if (a.tab.has_err) {
           // per-row RMS of err / (atol + rtol*max(|y0|,|y1|)) over all F columns (torchode rms_norm)
-          float q = 0.f;
+          __syncthreads();  // red free
 #pragma unroll
-          for (int ci = 0; ci < 2; ++ci) {
-            if (colv[ci]) {
-              const float bound = a.atol + a.rtol * fmaxf(fabsf(y[ci]), fabsf(y1[ci]));
-              const float z = er[ci] / bound;
-              q += z * z;
+          for (int h = 0; h < NH; ++h) {
+            float q = 0.f;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+              if (colv[ci]) {
+                const float bound = a.atol + a.rtol * fmaxf(fabsf(hs[h].y[ci]), fabsf(y1[h][ci]));
+                const float z = er[h][ci] / bound;
+                q += z * z;
+              }
             }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if ((tid & 63) < 16) hs[h].red[(tid >> 6) * 16 + ks] = q;
           }
-          q += __shfl_xor(q, 16, 64);
-          q += __shfl_xor(q, 32, 64);
-          __syncthreads();  // red/nrm free
-          if ((tid & 63) < 16) red[(tid >> 6) * 16 + ks] = q;
           __syncthreads();
           ++c.epoch;
-          if (tid < R) {
-            const float s = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
-            put(cur_buf(c) + tid * INTEG_MEMBERS + cu, s, c.epoch, c.local);
-          }
-          gather<MAXG>(c, R * INTEG_MEMBERS, nrm);
-          float tot = 0.f;
-          const int rr = has_row ? ks : 0;
-          for (int m = 0; m < INTEG_MEMBERS; ++m) tot += nrm[rr * INTEG_MEMBERS + m];
-          const float ratio = sqrtf(tot / (float)F);
-          accept = ratio < 1.0f;
-          float factor = 0.9f * powf(ratio, inv_order);
-          factor = fminf(fmaxf(factor, 0.2f), 10.0f);
-          dtn = dt * factor;
-        } else {
-          dtn = dt;
-        }
-        const bool upd = accept && running;
-        if (running) ++n_steps;
-        if (upd) {
-          ++n_acc;
-          y[0] = y1[0];
-          y[1] = y1[1];
-          if (a.tab.fsal) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j)
-              if (j == S - 1) {
-                k[0][0] = k[j][0];
-                k[0][1] = k[j][1];
-              }
+          for (int h = 0; h < NH; ++h) {
+            if (hs[h].active && tid < R) {
+              const float* red = hs[h].red;
+              const float s = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+              put(buf_of(hs[h], c.epoch) + tid * INTEG_MEMBERS + cu, s, c.epoch, c.local);
+            }
           }
-        }
-        if (fixed) {
-          if (--sub_left <= 0) running = false;
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
+            if (!hs[h].active) continue;
+            gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, R * INTEG_MEMBERS, hs[h].nrm);
+            float tot = 0.f;
+            const int rr = hs[h].has_row ? ks : 0;
+            for (int m = 0; m < INTEG_MEMBERS; ++m) tot += hs[h].nrm[rr * INTEG_MEMBERS + m];
+            const float ratio = sqrtf(tot / (float)F);
+            accept[h] = ratio < 1.0f;
+            float factor = 0.9f * powf(ratio, inv_order);
+            factor = fminf(fmaxf(factor, 0.2f), 10.0f);
+            hs[h].dtn = hs[h].dt * factor;
+          }
         } else {
-          if (upd) t = last ? t1 : t + dt;
-          running = row_valid && (t < t1);
-          const float span = t1 - t;
-          last = dtn >= span;
-          dt = last ? span : dtn;
+#pragma unroll
+          for (int h = 0; h < NH; ++h) hs[h].dtn = hs[h].dt;
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          Half<RT>& H = hs[h];
+          const bool upd = accept[h] && H.running;
+          if (H.running) ++H.n_steps;
+          if (upd) {
+            ++H.n_acc;
+            H.y[0] = y1[h][0];
+            H.y[1] = y1[h][1];
+            if (a.tab.fsal) {
+#pragma unroll
+              for (int j = 0; j < 7; ++j)
+                if (j == S - 1) {
+                  H.k[0][0] = H.k[j][0];
+                  H.k[0][1] = H.k[j][1];
+                }
+            }
+          }
+          if (fixed) {
+            if (--H.sub_left <= 0) H.running = false;
+          } else {
+            if (upd) H.t = H.last ? H.t1 : H.t + H.dt;
+            H.running = H.row_valid && (H.t < H.t1);
+            const float span = H.t1 - H.t;
+            H.last = H.dtn >= span;
+            H.dt = H.last ? span : H.dtn;
+          }
         }
         have_k1 = a.tab.fsal != 0;
       }
@@ -602,84 +687,89 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
     if (!seq_mode || c.failed) break;
 
     // ======================= RNN phase =======================
-    // 1. all-gather the evolved states h~ [R][F] -> hst
+    // 1. all-gather the evolved states h~ [R][F] of each half -> hst
     ++c.epoch;
-    if (has_row) {
-      u64* buf = cur_buf(c);
 #pragma unroll
-      for (int ci = 0; ci < 2; ++ci)
-        if (colv[ci]) put(buf + ks * F + colg[ci], y[ci], c.epoch, c.local);
+    for (int h = 0; h < NH; ++h) {
+      if (hs[h].active && hs[h].has_row) {
+        u64* buf = buf_of(hs[h], c.epoch);
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+          if (colv[ci]) put(buf + ks * F + colg[ci], hs[h].y[ci], c.epoch, c.local);
+      }
     }
-    gather<MAXG>(c, R * F, hst);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (hs[h].active) gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, R * F, hs[h].hst);
     const int NCV = a.rnn_vcols * NCF;
     for (int l = 0; l < a.L; ++l) {
-      if (l == 0) {
-        __syncthreads();
-        for (int i = tid; i < BPG * F; i += 256) {
-          const int bi = i / F;
-          const int b = a.b_begin + g * BPG + bi;
-          xin[i] = (b < a.b_end) ? a.fused[((size_t)b * a.P + it) * F + (i - bi * F)] : 0.f;
-        }
-        __syncthreads();
-      }
+      const bool more = l + 1 < a.L;
       const float* wsl = a.rw[l] + (size_t)cu * NCV * 2 * F;
-      const unsigned long long sr0 = STAMP_NOW();
-      for (int pass = 0; pass * 32 < NCV; ++pass) {
-        float acc[2];
-        layer<RT, false>(wsl, NCV, F, xin, F, F, hst + (size_t)l * BPG * F, F, BPG, pass * 32 + slot, ks, acc);
-        if (ks < BPG) {
+      const float* rb = a.rb[l];
 #pragma unroll
-          for (int ci = 0; ci < 2; ++ci) {
-            const int cl = pass * 32 + ci * 16 + slot;
-            if (cl < NCV) pre[cl * RT + ks] = acc[ci];
+      for (int h = 0; h < NH; ++h) {
+        Half<RT>& H = hs[h];
+        if (!H.active) continue;
+        const int first = a.b_begin + (g * NH + h) * BPH;
+        if (l == 0) {
+          __syncthreads();
+          for (int i = tid; i < BPH * F; i += 256) {
+            const int bi = i / F;
+            const int b = first + bi;
+            H.xin[i] = (b < a.b_end) ? a.fused[((size_t)b * a.P + it) * F + (i - bi * F)] : 0.f;
+          }
+          __syncthreads();
+        } else {
+          gather<MAXG>(c, buf_of(H, c.epoch), c.epoch, BPH * F, H.xin);
+        }
+        const unsigned long long sr0 = STAMP_NOW();
+        for (int pass = 0; pass * 32 < NCV; ++pass) {
+          float res[2];
+          layer<RT, false>(wsl, NCV, F, H.xin, F, F, H.hst + (size_t)l * BPH * F, F, BPH, pass * 32 + slot, ks, res);
+          if (ks < BPH) {
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+              const int cl = pass * 32 + ci * 16 + slot;
+              if (cl < NCV) H.pre[cl * RT + ks] = res[ci];
+            }
           }
         }
-      }
-      STAMP_ADD(c.t_rnn, sr0);
-      __syncthreads();
-      float hn[2] = {0.f, 0.f};
-      if (ks < BPG) {
-        const int b = a.b_begin + g * BPG + ks;
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci) {
-          const int ul = ci * 16 + slot;
-          if (ul >= NCF) continue;
-          const int ug = cu * NCF + ul;
-          const float* rb = a.rb[l];
-          float h;
-          if (a.rnn_type == 0) {
-            h = tanhf(pre[ul * RT + ks] + rb[ug]);
-          } else {
-            const float rg = sigmoidf_(pre[ul * RT + ks] + rb[ug]);
-            const float zg = sigmoidf_(pre[(NCF + ul) * RT + ks] + rb[F + ug]);
-            const float ng = tanhf(pre[(2 * NCF + ul) * RT + ks] + rb[2 * F + ug] +
-                                   rg * (pre[(3 * NCF + ul) * RT + ks] + rb[3 * F + ug]));
-            const float hp = hst[((size_t)l * BPG + ks) * F + ug];
-            h = (1.f - zg) * ng + zg * hp;
-          }
-          hn[ci] = h;
-          mv[(l * BPG + ks) * 32 + ul] = h;
-          if (l == a.L - 1 && b < a.b_end) a.out_seq[((size_t)b * a.P + it) * F + ug] = h;
-        }
-      }
-      if (l + 1 < a.L) {
-        ++c.epoch;
-        if (ks < BPG) {
-          u64* buf = cur_buf(c);
+        STAMP_ADD(c.t_rnn, sr0);
+        __syncthreads();
+        if (ks < BPH) {
+          const int b = first + ks;
 #pragma unroll
           for (int ci = 0; ci < 2; ++ci) {
             const int ul = ci * 16 + slot;
-            if (ul < NCF) put(buf + ks * F + cu * NCF + ul, hn[ci], c.epoch, c.local);
+            if (ul >= NCF) continue;
+            const int ug = cu * NCF + ul;
+            float hv;
+            if (a.rnn_type == 0) {
+              hv = tanhf(H.pre[ul * RT + ks] + rb[ug]);
+            } else {
+              const float rg = sigmoidf_(H.pre[ul * RT + ks] + rb[ug]);
+              const float zg = sigmoidf_(H.pre[(NCF + ul) * RT + ks] + rb[F + ug]);
+              const float ng = tanhf(H.pre[(2 * NCF + ul) * RT + ks] + rb[2 * F + ug] +
+                                     rg * (H.pre[(3 * NCF + ul) * RT + ks] + rb[3 * F + ug]));
+              const float hp = H.hst[((size_t)l * BPH + ks) * F + ug];
+              hv = (1.f - zg) * ng + zg * hp;
+            }
+            H.mv[(l * BPH + ks) * 32 + ul] = hv;
+            if (!more && b < a.b_end) a.out_seq[((size_t)b * a.P + it) * F + ug] = hv;
+            if (more) put(buf_of(H, c.epoch + 1) + ks * F + ug, hv, c.epoch + 1, c.local);
           }
         }
-        gather<MAXG>(c, BPG * F, xin);
       }
+      if (more) ++c.epoch;
     }
     __syncthreads();
-    if (has_row) {
 #pragma unroll
-      for (int ci = 0; ci < 2; ++ci)
-        if (colv[ci]) y[ci] = mv[ks * 32 + ci * 16 + slot];
+    for (int h = 0; h < NH; ++h) {
+      if (hs[h].has_row) {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+          if (colv[ci]) hs[h].y[ci] = hs[h].mv[ks * 32 + ci * 16 + slot];
+      }
     }
     __syncthreads();
   }
@@ -696,43 +786,43 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   (void)t_begin;
 #endif
   // ---- outputs
-  if (row_valid && !c.failed) {
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const Half<RT>& H = hs[h];
+    if (!H.row_valid || c.failed) continue;
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
       if (!colv[ci]) continue;
-      if (seq_mode) a.hT[(size_t)grow * F + colg[ci]] = y[ci];
-      else a.y_out[(size_t)grow * F + colg[ci]] = y[ci];
+      if (seq_mode) a.hT[(size_t)H.grow * F + colg[ci]] = H.y[ci];
+      else a.y_out[(size_t)H.grow * F + colg[ci]] = H.y[ci];
     }
     if (a.stats && cu == 0 && slot == 0) {
-      a.stats[2 * grow] = n_steps;
-      a.stats[2 * grow + 1] = n_acc;
+      a.stats[2 * H.grow] = H.n_steps;
+      a.stats[2 * H.grow + 1] = H.n_acc;
     }
   }
 }
 
+template <int RT>
+static int launch_rt(const IntegArgs& a, size_t lds_bytes, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_kernel<RT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(integrator_kernel<RT>, dim3(INTEG_GROUPS * INTEG_MEMBERS), dim3(256), lds_bytes, st, a);
+  return 0;
+}
+
 int launch_integrator(const IntegArgs& a, int rt, size_t lds_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(INTEG_GROUPS * INTEG_MEMBERS), block(256);
-  const int max_dyn = 160 * 1024 - 1024;  // the kernel also owns a little static LDS
-  static bool attr4 = false, attr8 = false;
-  hipError_t e = hipSuccess;
   (void)hipGetLastError();  // do not inherit a stale error from an unrelated call
-  if (rt <= 4) {
-    if (!attr4) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-      if (e != hipSuccess) return (int)e;
-      attr4 = true;
-    }
-    hipLaunchKernelGGL(integrator_kernel<4>, grid, block, lds_bytes, st, a);
-  } else {
-    if (!attr8) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_kernel<8>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
-      if (e != hipSuccess) return (int)e;
-      attr8 = true;
-    }
-    hipLaunchKernelGGL(integrator_kernel<8>, grid, block, lds_bytes, st, a);
-  }
+  int e;
+  if (rt <= 2) e = launch_rt<2>(a, lds_bytes, st);
+  else if (rt <= 4) e = launch_rt<4>(a, lds_bytes, st);
+  else e = launch_rt<8>(a, lds_bytes, st);
+  if (e) return e;
   return (int)hipGetLastError();
 }
