@@ -592,6 +592,11 @@ static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int su
     const int n = (p->dims[l + 1] / INTEG_MEMBERS) * p->dims[l];
     if (n <= budget) { a.w_lds_off[l] = woff; woff += n; budget -= n; }
   }
+  a.shape_id = (p->nlin == 4 && a.F == 768 && a.H == 512) ? 1 : 0;
+  // one slice that did not fit may live in registers instead (one column slot per thread, <= 16 chunks of 64 inputs)
+  a.w_reg_layer = -1;
+  for (int l = 0; l < p->nlin; ++l)
+    if (a.w_lds_off[l] < 0 && p->dims[l + 1] / INTEG_MEMBERS <= 16 && p->dims[l] / 64 <= 16) { a.w_reg_layer = l; break; }
   *lds_bytes = (size_t)(off + woff) * sizeof(float);
   return 0;
 }

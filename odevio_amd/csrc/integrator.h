@@ -6,7 +6,9 @@
 #define INTEG_MAX_L 4      // RNN layers
 #define INTEG_MEMBERS 32   // workgroups (CUs) per row group = one XCD under round-robin dispatch
 #define INTEG_GROUPS 8
-#define INTEG_HALVES 2     // independent row sets a workgroup alternates between (latency hiding)
+#ifndef INTEG_HALVES
+#define INTEG_HALVES 1     // independent row sets a workgroup alternates between (2 = latency-hiding experiment)
+#endif
 #define INTEG_KMAX 1024    // widest vector exchanged between layers
 
 enum IntegMode { MODE_ODE_RNN = 0, MODE_RNN_ONLY = 1, MODE_ODE_STEPS = 2, MODE_FEVAL = 3 };
@@ -28,7 +30,9 @@ struct IntegArgs {
   int dims[INTEG_MAX_LIN + 1];            // F, H, ..., H, F
   const float* w[INTEG_MAX_LIN];          // per-member slices, layout [member][j][col][ks][4]
   const float* b[INTEG_MAX_LIN];          // full bias vectors
-  int w_lds_off[INTEG_MAX_LIN];           // float offset of the LDS-resident copy, or -1 = stream from L2
+  int w_lds_off[INTEG_MAX_LIN];           // float offset of the LDS-resident copy, or -1 = not in LDS
+  int shape_id;                           // 1: F=768, H=512, 4 Linears (statically unrolled layer products); 0: generic
+  int w_reg_layer;                        // layer whose slice lives in registers for the whole launch, or -1
   // ---- RNN stack
   int rnn_type, L, rnn_vcols;             // virtual columns per hidden unit: 1 (tanh RNN) or 4 (GRU: r, z, n_i, n_h)
   const float* rw[INTEG_MAX_L];           // [member][j][col][ks][4], K = 2F ([input | hidden])

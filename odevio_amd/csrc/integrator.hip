@@ -28,6 +28,8 @@
 // Thread map (256 threads): ks = tid & 15 is a K-slice during a layer product and the ROW a thread
 // owns afterwards; slot = tid >> 4 is a column slot.  State element (row, local col) lives on the
 // thread (ks = row, slot = col % 16) in register col / 16.
+#include <type_traits>
+
 #include "common.h"
 #include "integrator.h"
 
@@ -39,8 +41,8 @@ typedef unsigned long long u64;
 #define SPIN_TIMEOUT_TICKS 200000000ull  // 2 s of the 100 MHz s_memrealtime clock
 
 #ifdef ODEVIO_STAMPS
-#define STAMP_NOW() __builtin_amdgcn_s_memrealtime()
-#define STAMP_ADD(acc, t0) (acc) += __builtin_amdgcn_s_memrealtime() - (t0)
+#define STAMP_NOW() __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(acc, t0) (acc) += __builtin_amdgcn_s_memtime() - (t0)
 #else
 #define STAMP_NOW() 0ull
 #define STAMP_ADD(acc, t0) (void)(t0)
@@ -182,11 +184,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int RT, bool TWO>
 __device__ __forceinline__ void layer_seg(const float* __restrict__ wbase, int NC, int jbase, int nseg,
-                                          const float* xs, int ld, int nr, int c0, int c1, int ks,
+                                          const float* xs, const int (&roff)[RT], int c0, int c1, int ks,
                                           f32x2 (&acc)[2][RT]) {
-  int roff[RT];
-#pragma unroll
-  for (int r = 0; r < RT; ++r) roff[r] = (r < nr ? r : nr - 1) * ld;
   const float* w0p = wbase + (((size_t)jbase * NC + c0) * 16 + ks) * 4;
   const float* w1p = wbase + (((size_t)jbase * NC + c1) * 16 + ks) * 4;
   const size_t wstep = (size_t)NC * 64;
@@ -232,13 +231,63 @@ __device__ __forceinline__ void layer_seg(const float* __restrict__ wbase, int N
   }
 }
 
+// Fully static form for a known layer shape (NSEG chunks, NCT columns per member): straight-line code, every
+// LDS / L2 address is a lane base plus an immediate, no loop control and no guards - at one wave per SIMD the
+// instruction count IS the latency, and the generic ring above spends ~5x more instructions than arithmetic.
+template <int RT, bool TWO, int NSEG, int NCT>
+__device__ __forceinline__ void layer_seg_static(const float* __restrict__ wbase, int jbase, const float* xs,
+                                                 const int (&roff)[RT], int c0, int c1, int ks,
+                                                 f32x2 (&acc)[2][RT]) {
+  const float* w0p = wbase + (((size_t)jbase * NCT + c0) * 16 + ks) * 4;
+  const float* w1p = wbase + (((size_t)jbase * NCT + c1) * 16 + ks) * 4;
+  xs += 4 * ks;
+#pragma unroll
+  for (int j = 0; j < NSEG; ++j) {
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w0p + j * NCT * 64);
+    f32x4 w1 = w0;
+    if (TWO) w1 = *reinterpret_cast<const f32x4*>(w1p + j * NCT * 64);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xs + j * 64 + roff[r]);
+      acc[0][r] = __builtin_elementwise_fma(w0.lo, x.lo, acc[0][r]);
+      acc[0][r] = __builtin_elementwise_fma(w0.hi, x.hi, acc[0][r]);
+      if (TWO) {
+        acc[1][r] = __builtin_elementwise_fma(w1.lo, x.lo, acc[1][r]);
+        acc[1][r] = __builtin_elementwise_fma(w1.hi, x.hi, acc[1][r]);
+      }
+    }
+  }
+}
+
+// The same product with this thread's weights already in registers (one column, <= LAYER_REG_NJ chunks): the
+// one ODEFunc slice that does not fit in LDS beside the others is loaded ONCE per launch instead of being
+// streamed from L2 at every stage (an L2 round trip per chunk is ~1 us of exposed latency per evaluation).
+#define LAYER_REG_NJ 16
+template <int RT>
+__device__ __forceinline__ void layer_seg_reg(const f32x4 (&wr)[LAYER_REG_NJ], int nseg, const float* xs,
+                                              const int (&roff)[RT], int ks, f32x2 (&acc)[2][RT]) {
+  xs += 4 * ks;
+#pragma unroll
+  for (int j = 0; j < LAYER_REG_NJ; ++j) {
+    if (j < nseg) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(xs + j * 64 + roff[r]);
+        acc[0][r] = __builtin_elementwise_fma(wr[j].lo, x.lo, acc[0][r]);
+        acc[0][r] = __builtin_elementwise_fma(wr[j].hi, x.hi, acc[0][r]);
+      }
+    }
+  }
+}
+
 // One layer product for this member: acc[c][r] = sum_k W[col_c][k] * x[r][k], c = 0,1 (local columns
-// col0 = pass*32 + slot and col0 + 16), r < RT.  Inputs k < K1 come from xa, the rest from xb.
+// col0 = pass*32 + slot and col0 + 16), r < RT.  Row r reads its first K1 inputs at xa + offa[r] and the
+// remaining K2 at xb + offb[r].  wr != nullptr selects the register-resident weights (K2 == 0, one column).
 // On return res[c] is the total of row (ks mod RT) for column c (reduce_rows).
-template <int RT, bool WLDS>
-__device__ __forceinline__ void layer(const float* __restrict__ wbase, int NC, int K1, const float* xa, int lda,
-                                      int K2, const float* xb, int ldb, int nr, int col0, int ks,
-                                      float (&res)[2]) {
+template <int RT, int NSEG1 = 0, int NCT = 0>
+__device__ __forceinline__ void layer(const float* __restrict__ wbase, const f32x4 (*wr)[LAYER_REG_NJ], int NC, int K1,
+                                      const float* xa, const int (&offa)[RT], int K2, const float* xb,
+                                      const int (&offb)[RT], int col0, int ks, float (&res)[2]) {
   f32x2 acc[2][RT];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -249,9 +298,36 @@ __device__ __forceinline__ void layer(const float* __restrict__ wbase, int NC, i
   // a wave holds 4 consecutive column slots, so "this wave has a second column" is wave-uniform
   const bool two = __builtin_amdgcn_readfirstlane((int)(((col0 & ~3) + 16) < NC)) != 0;
   const int nj1 = K1 >> 6, nj2 = K2 >> 6;
-  if (two) {
-    layer_seg<RT, true>(wbase, NC, 0, nj1, xa, lda, nr, c0, c1, ks, acc);
-    if (nj2) layer_seg<RT, true>(wbase, NC, nj1, nj2, xb, ldb, nr, c0, c1, ks, acc);
+  if (NSEG1 > 0 && !wr) {
+    // static shape (K2 == 0 by construction of the callers)
+    if (two) {
+      layer_seg_static<RT, true, NSEG1, NCT>(wbase, 0, xa, offa, c0, c1, ks, acc);
+      float s0[RT], s1[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        s0[r] = acc[0][r].x + acc[0][r].y;
+        s1[r] = acc[1][r].x + acc[1][r].y;
+      }
+      res[0] = reduce_rows<RT>(s0, ks);
+      res[1] = reduce_rows<RT>(s1, ks);
+    } else {
+      layer_seg_static<RT, false, NSEG1, NCT>(wbase, 0, xa, offa, c0, c1, ks, acc);
+      float s0[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) s0[r] = acc[0][r].x + acc[0][r].y;
+      res[0] = reduce_rows<RT>(s0, ks);
+      res[1] = 0.f;
+    }
+  } else if (wr) {
+    layer_seg_reg<RT>(*wr, nj1, xa, offa, ks, acc);
+    float s0[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) s0[r] = acc[0][r].x + acc[0][r].y;
+    res[0] = reduce_rows<RT>(s0, ks);
+    res[1] = 0.f;
+  } else if (two) {
+    layer_seg<RT, true>(wbase, NC, 0, nj1, xa, offa, c0, c1, ks, acc);
+    if (nj2) layer_seg<RT, true>(wbase, NC, nj1, nj2, xb, offb, c0, c1, ks, acc);
     float s0[RT], s1[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
@@ -261,8 +337,8 @@ __device__ __forceinline__ void layer(const float* __restrict__ wbase, int NC, i
     res[0] = reduce_rows<RT>(s0, ks);
     res[1] = reduce_rows<RT>(s1, ks);
   } else {
-    layer_seg<RT, false>(wbase, NC, 0, nj1, xa, lda, nr, c0, c1, ks, acc);
-    if (nj2) layer_seg<RT, false>(wbase, NC, nj1, nj2, xb, ldb, nr, c0, c1, ks, acc);
+    layer_seg<RT, false>(wbase, NC, 0, nj1, xa, offa, c0, c1, ks, acc);
+    if (nj2) layer_seg<RT, false>(wbase, NC, nj1, nj2, xb, offb, c0, c1, ks, acc);
     float s0[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) s0[r] = acc[0][r].x + acc[0][r].y;
@@ -421,10 +497,24 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
     for (int i = tid * 4; i < n; i += 1024)
       *reinterpret_cast<f32x4*>(dstw + i) = *reinterpret_cast<const f32x4*>(src + i);
   }
+  // ---- the slice that does not fit in LDS: this thread's weights of that layer, once, into registers
+  f32x4 wreg[LAYER_REG_NJ];
+#pragma unroll
+  for (int j = 0; j < LAYER_REG_NJ; ++j) wreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (a.w_reg_layer >= 0) {
+    const int l = a.w_reg_layer;
+    const int NC = a.dims[l + 1] / INTEG_MEMBERS, K = a.dims[l];
+    const float* src = a.w[l] + (size_t)cu * NC * K;
+    const int cc = slot < NC ? slot : NC - 1;
+#pragma unroll
+    for (int j = 0; j < LAYER_REG_NJ; ++j)
+      if (j < (K >> 6)) wreg[j] = *reinterpret_cast<const f32x4*>(src + (((size_t)j * NC + cc) * 16 + ks) * 4);
+  }
+  int off_ode[RT];  // row offsets of an ODEFunc layer input [R][K] are set per layer below
   __syncthreads();
 
   // vector field for both halves: stage values sv[h] (this thread's elements) -> ko[h]
-  auto feval = [&](const float (&sv)[NH][2], float (&ko)[NH][2]) {
+  auto feval = [&](const float (&sv)[NH][2], float (&ko)[NH][2]) __attribute__((always_inline)) {
     ++c.epoch;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -435,7 +525,8 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
           if (colv[ci]) put(buf + ks * F + colg[ci], sv[h][ci], c.epoch, c.local);
       }
     }
-    for (int l = 0; l < a.nlin; ++l) {
+    auto do_layer = [&](auto nseg_c, auto nct_c, int l) __attribute__((always_inline)) {
+      constexpr int NSEG = decltype(nseg_c)::value, NCT = decltype(nct_c)::value;
       const int K = a.dims[l], N = a.dims[l + 1];
       const int NC = N / INTEG_MEMBERS;
       const bool more = l + 1 < a.nlin;
@@ -445,10 +536,14 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
         gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, R * K, hs[h].xin);
         float res[2];
         const unsigned long long sl0 = STAMP_NOW();
+#pragma unroll
+        for (int r = 0; r < RT; ++r) off_ode[r] = (r < R ? r : R - 1) * K;
         if (a.w_lds_off[l] >= 0)
-          layer<RT, true>(wl + a.w_lds_off[l], NC, K, hs[h].xin, K, 0, hs[h].xin, K, R, slot, ks, res);
+          layer<RT, NSEG, NCT>(wl + a.w_lds_off[l], nullptr, NC, K, hs[h].xin, off_ode, 0, hs[h].xin, off_ode, slot, ks, res);
+        else if (l == a.w_reg_layer)
+          layer<RT>(nullptr, &wreg, NC, K, hs[h].xin, off_ode, 0, hs[h].xin, off_ode, slot, ks, res);
         else
-          layer<RT, false>(a.w[l] + (size_t)cu * NC * K, NC, K, hs[h].xin, K, 0, hs[h].xin, K, R, slot, ks, res);
+          layer<RT>(a.w[l] + (size_t)cu * NC * K, nullptr, NC, K, hs[h].xin, off_ode, 0, hs[h].xin, off_ode, slot, ks, res);
         STAMP_ADD(c.t_layer, sl0);
         float v[2];
 #pragma unroll
@@ -468,6 +563,16 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
         }
       }
       if (more) ++c.epoch;
+    };
+    using std::integral_constant;
+    if (a.shape_id == 1) {
+      // ODEFunc 768 -> 512 -> 512 -> 512 -> 768 (reference defaults, scripts/config.py:50-51,62-63)
+      do_layer(integral_constant<int, 12>{}, integral_constant<int, 16>{}, 0);
+      do_layer(integral_constant<int, 8>{}, integral_constant<int, 16>{}, 1);
+      do_layer(integral_constant<int, 8>{}, integral_constant<int, 16>{}, 2);
+      do_layer(integral_constant<int, 8>{}, integral_constant<int, 24>{}, 3);
+    } else {
+      for (int l = 0; l < a.nlin; ++l) do_layer(integral_constant<int, 0>{}, integral_constant<int, 0>{}, l);
     }
   };
 
@@ -702,40 +807,90 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
     for (int h = 0; h < NH; ++h)
       if (hs[h].active) gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, R * F, hs[h].hst);
     const int NCV = a.rnn_vcols * NCF;
+    // Both halves share one pass over the streamed RNN weights: rows r = h*RT + bi of a 2*RT-row product read
+    // their inputs from their own half's LDS block (the blocks sit lds_half_stride floats apart).
+    constexpr bool JOINT = NH == 2 && RT <= 4;
+    constexpr int RR = JOINT ? 2 * RT : RT;
     for (int l = 0; l < a.L; ++l) {
       const bool more = l + 1 < a.L;
       const float* wsl = a.rw[l] + (size_t)cu * NCV * 2 * F;
       const float* rb = a.rb[l];
+      // ---- inputs of this layer: the fused features (l = 0) or the gathered h' of the layer below
+      if (l == 0) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          if (!hs[h].active) continue;
+          const int first = a.b_begin + (g * NH + h) * BPH;
+          for (int i = tid; i < BPH * F; i += 256) {
+            const int bi = i / F;
+            const int b = first + bi;
+            hs[h].xin[i] = (b < a.b_end) ? a.fused[((size_t)b * a.P + it) * F + (i - bi * F)] : 0.f;
+          }
+        }
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          if (hs[h].active) gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, BPH * F, hs[h].xin);
+      }
+      // ---- pre-activations
+      const unsigned long long sr0 = STAMP_NOW();
+      if (JOINT) {
+        int offa[RR], offb[RR];
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+          const int hh = (r / RT) < NH && (r / RT == 0 ? hs[0].active : hs[NH - 1].active) ? r / RT : 0;
+          const int bi = (r % RT) < BPH ? (r % RT) : BPH - 1;
+          offa[r] = hh * a.lds_half_stride + bi * F;
+          offb[r] = hh * a.lds_half_stride + (l * BPH + bi) * F;
+        }
+        const int kh = ks / RT, kb = ks - kh * RT;  // the (half, sequence) whose total reduce_rows leaves on this lane
+        const bool mine = kh < NH && kb < BPH && (kh == 0 ? hs[0].active : hs[NH - 1].active);
+        float* pre_k = hs[0].pre + kh * a.lds_half_stride;
+        for (int pass = 0; pass * 32 < NCV; ++pass) {
+          float res[2];
+          layer<RR>(wsl, nullptr, NCV, F, hs[0].xin, offa, F, hs[0].hst, offb, pass * 32 + slot, ks, res);
+          if (mine) {
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+              const int cl = pass * 32 + ci * 16 + slot;
+              if (cl < NCV) pre_k[cl * RT + kb] = res[ci];
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          if (!hs[h].active) continue;
+          int offa[RT], offb[RT];
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            const int bi = r < BPH ? r : BPH - 1;
+            offa[r] = bi * F;
+            offb[r] = (l * BPH + bi) * F;
+          }
+          for (int pass = 0; pass * 32 < NCV; ++pass) {
+            float res[2];
+            layer<RT>(wsl, nullptr, NCV, F, hs[h].xin, offa, F, hs[h].hst, offb, pass * 32 + slot, ks, res);
+            if (ks < BPH) {
+#pragma unroll
+              for (int ci = 0; ci < 2; ++ci) {
+                const int cl = pass * 32 + ci * 16 + slot;
+                if (cl < NCV) hs[h].pre[cl * RT + ks] = res[ci];
+              }
+            }
+          }
+        }
+      }
+      STAMP_ADD(c.t_rnn, sr0);
+      __syncthreads();
+      // ---- gates / tanh on the owning lanes, new hidden state
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         Half<RT>& H = hs[h];
         if (!H.active) continue;
         const int first = a.b_begin + (g * NH + h) * BPH;
-        if (l == 0) {
-          __syncthreads();
-          for (int i = tid; i < BPH * F; i += 256) {
-            const int bi = i / F;
-            const int b = first + bi;
-            H.xin[i] = (b < a.b_end) ? a.fused[((size_t)b * a.P + it) * F + (i - bi * F)] : 0.f;
-          }
-          __syncthreads();
-        } else {
-          gather<MAXG>(c, buf_of(H, c.epoch), c.epoch, BPH * F, H.xin);
-        }
-        const unsigned long long sr0 = STAMP_NOW();
-        for (int pass = 0; pass * 32 < NCV; ++pass) {
-          float res[2];
-          layer<RT, false>(wsl, NCV, F, H.xin, F, F, H.hst + (size_t)l * BPH * F, F, BPH, pass * 32 + slot, ks, res);
-          if (ks < BPH) {
-#pragma unroll
-            for (int ci = 0; ci < 2; ++ci) {
-              const int cl = pass * 32 + ci * 16 + slot;
-              if (cl < NCV) H.pre[cl * RT + ks] = res[ci];
-            }
-          }
-        }
-        STAMP_ADD(c.t_rnn, sr0);
-        __syncthreads();
         if (ks < BPH) {
           const int b = first + ks;
 #pragma unroll
@@ -776,7 +931,7 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
 
 #ifdef ODEVIO_STAMPS
   if (a.dbg && g == 0 && cu == 0 && tid == 0) {
-    a.dbg[0] = __builtin_amdgcn_s_memrealtime() - t_begin;
+    a.dbg[0] = __builtin_amdgcn_s_memtime() - t_begin;
     a.dbg[1] = c.t_gather;
     a.dbg[2] = c.t_layer;
     a.dbg[3] = c.t_rnn;

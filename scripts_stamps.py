@@ -17,5 +17,12 @@ for solver, B, safe in (("rk4", 16, "0"), ("rk4", 16, "1"), ("dopri5", 16, "0"),
     _lib.check(m._lib.odevio_debug_stamps(m._plan, ctypes.cast(out, ctypes.c_void_p), None))
     tot, tg, tl, tr, ng = [int(x) for x in out[:5]]
     local = [(int(out[5]) >> (8 * g)) & 1 for g in range(8)]
-    print(f"{solver} B={B} safe={safe}: kernel {tot/100:.1f} us; gathers {ng} total {tg/100:.1f} us ({tg/max(ng,1)/100:.2f} us each); "
-          f"ode layers {tl/100:.1f} us; rnn layers {tr/100:.1f} us; other {(tot-tg-tl-tr)/100:.1f} us; L2-local groups {local}")
+    # production library timing of the same call (events on the current stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        m.pose_net(fv, fi, ts)
+    e1.record(); torch.cuda.synchronize()
+    print(f"   pose_net (stamps build) {e0.elapsed_time(e1)/20*1000:.1f} us per call")
+    print(f"{solver} B={B} safe={safe}: kernel {tot} cyc; gathers {ng} total {100*tg/tot:.1f}% ({tg/max(ng,1):.0f} cyc each); "
+          f"ode layers {100*tl/tot:.1f}%; rnn layers {100*tr/tot:.1f}%; other {100*(tot-tg-tl-tr)/tot:.1f}%; L2-local groups {local}")
