@@ -142,16 +142,26 @@ static int bn_fold(const WeightTable& wt, const std::string& bn, int c, const st
 }
 
 // [N][K] row-major -> per-member slices [member][j][col][ks][4] (integrator.hip, layer()).
-static void shard_columns(const std::vector<float>& W, int N, int K, std::vector<float>& out) {
+// The K axis is given as segments (each padded with zeros to a multiple of 256 = 64 lanes x 4 floats): lane l of
+// a wave multiplies inputs 256j + 4l .. 4l+3 of chunk j, so its weights for (chunk, column) are one float4.
+static int pad256(int k) { return (k + 255) & ~255; }
+static void shard_columns(const std::vector<float>& W, int N, const std::vector<int>& segs, std::vector<float>& out) {
   const int NC = N / INTEG_MEMBERS;
-  out.assign((size_t)N * K, 0.f);
+  int K = 0, Kp = 0;
+  for (int s : segs) { K += s; Kp += pad256(s); }
+  out.assign((size_t)N * Kp, 0.f);
   for (int m = 0; m < INTEG_MEMBERS; ++m)
-    for (int j = 0; j < K / 64; ++j)
-      for (int col = 0; col < NC; ++col)
-        for (int ks = 0; ks < 16; ++ks)
-          for (int e = 0; e < 4; ++e)
-            out[(size_t)m * NC * K + (((size_t)j * NC + col) * 16 + ks) * 4 + e] =
-                W[(size_t)(m * NC + col) * K + j * 64 + ks * 4 + e];
+    for (int col = 0; col < NC; ++col) {
+      int k0 = 0, j0 = 0;
+      for (int s : segs) {
+        for (int k = 0; k < s; ++k) {
+          const int j = j0 + k / 256, lane = (k % 256) / 4, e = k % 4;
+          out[(size_t)m * NC * Kp + (((size_t)j * NC + col) * 64 + lane) * 4 + e] = W[(size_t)(m * NC + col) * K + k0 + k];
+        }
+        k0 += s;
+        j0 += pad256(s) / 256;
+      }
+    }
 }
 
 extern "C" int odevio_version(void) { return ODEVIO_VERSION; }
@@ -307,7 +317,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       const std::string pre = "Pose_net.ode_func.net." + std::to_string(2 * l);
       const int N = p->dims[l + 1], K = p->dims[l];
       TRY(wt.get(pre + ".weight", (int64_t)N * K, w));
-      shard_columns(w, N, K, t);
+      shard_columns(w, N, {K}, t);
       TRY(upload(p, &p->ode_w[l], t, st));
       TRY(wt.get(pre + ".bias", N, bias));
       TRY(upload(p, &p->ode_b[l], bias, st));
@@ -351,14 +361,14 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
               vb[(size_t)3 * F + u] = bhh[(size_t)2 * F + u];
             }
           }
-      shard_columns(vm, V * F, 2 * F, t);
+      shard_columns(vm, V * F, {F, F}, t);
       TRY(upload(p, &p->rnn_w[l], t, st));
       TRY(upload(p, &p->rnn_b[l], vb, st));
     }
   }
   // ---- exchange buffers + status
   p->xstride = 8 * INTEG_KMAX;
-  TRY(dev_alloc(p, (void**)&p->xbuf, (size_t)INTEG_GROUPS * INTEG_HALVES * 2 * p->xstride * sizeof(unsigned long long)));
+  TRY(dev_alloc(p, (void**)&p->xbuf, (size_t)INTEG_GROUPS * 2 * p->xstride * sizeof(unsigned long long)));
   TRY(dev_alloc(p, (void**)&p->status, 128));
   HIPCHK(hipMemsetAsync(p->status, 0, 128, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -567,36 +577,27 @@ static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int su
     const char* e = getenv("ODEVIO_SAFE_HANDOFF");
     a.allow_local = (e && e[0] == '1') ? 0 : 1;
   }
-  // LDS carve (floats)
-  int maxdim = a.F;
-  for (int l = 0; l <= p->nlin; ++l) maxdim = std::max(maxdim, p->dims[l]);
-  // per-half block: xin [rt][maxdim] | hst [rt][F] | misc (red 64, nrm rt*32, mv rt*32, pre 128*rt)
-  int hoff = rt * maxdim;
-  a.lds_hst = hoff; hoff += rt * a.F;
-  a.lds_misc = hoff; hoff += 64 + rt * 32 * 2 + 128 * rt;
-  hoff = (hoff + 3) & ~3;
-  a.lds_half0 = 0;
-  a.lds_half_stride = hoff;
-  int off = INTEG_HALVES * hoff;
-  a.lds_bias = off; off += INTEG_MAX_LIN * 32;
+  // LDS carve (floats); every K is padded to a multiple of 256
+  int maxdim = pad256(a.F);
+  for (int l = 0; l <= p->nlin; ++l) maxdim = std::max(maxdim, pad256(p->dims[l]));
+  int off = 0;
+  a.lds_xin = off; off += rt * maxdim;
+  a.lds_hst = off; off += rt * pad256(a.F);
+  a.lds_misc = off; off += 128 * rt + rt * 32 * 2 + 256 + INTEG_MAX_LIN * 32;  // lay, nrm, mv, qb, bia
+  off = (off + 3) & ~3;
   a.lds_w = off;
   int budget = (160 * 1024 - 1024) / 4 - off;  // 1 KB left for the kernel's static LDS (__syncthreads_or scratch)
   // keep the largest slices that fit resident; the rest stream from L2
   std::vector<int> order(p->nlin);
   for (int l = 0; l < p->nlin; ++l) order[l] = l;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-    return (size_t)p->dims[x] * p->dims[x + 1] > (size_t)p->dims[y] * p->dims[y + 1];
+    return (size_t)pad256(p->dims[x]) * p->dims[x + 1] > (size_t)pad256(p->dims[y]) * p->dims[y + 1];
   });
   int woff = 0;
   for (int l : order) {
-    const int n = (p->dims[l + 1] / INTEG_MEMBERS) * p->dims[l];
+    const int n = (p->dims[l + 1] / INTEG_MEMBERS) * pad256(p->dims[l]);
     if (n <= budget) { a.w_lds_off[l] = woff; woff += n; budget -= n; }
   }
-  a.shape_id = (p->nlin == 4 && a.F == 768 && a.H == 512) ? 1 : 0;
-  // one slice that did not fit may live in registers instead (one column slot per thread, <= 16 chunks of 64 inputs)
-  a.w_reg_layer = -1;
-  for (int l = 0; l < p->nlin; ++l)
-    if (a.w_lds_off[l] < 0 && p->dims[l + 1] / INTEG_MEMBERS <= 16 && p->dims[l] / 64 <= 16) { a.w_reg_layer = l; break; }
   *lds_bytes = (size_t)(off + woff) * sizeof(float);
   return 0;
 }
@@ -604,7 +605,7 @@ static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int su
 static int launch_integ(odevio_plan* p, IntegArgs& a, int rt, size_t lds, hipStream_t st) {
   if (p->n_cu < INTEG_GROUPS * INTEG_MEMBERS)
     return fail(ODEVIO_ERR_UNSUPPORTED, "persistent integrator needs %d CUs, device has %d", INTEG_GROUPS * INTEG_MEMBERS, p->n_cu);
-  HIPCHK(hipMemsetAsync(p->xbuf, 0, (size_t)INTEG_GROUPS * INTEG_HALVES * 2 * p->xstride * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(p->xbuf, 0, (size_t)INTEG_GROUPS * 2 * p->xstride * sizeof(unsigned long long), st));
   const int e = launch_integrator(a, rt, lds, st);
   if (e != 0) return fail(ODEVIO_ERR_HIP, "integrator launch failed: %s (lds %zu B)", hipGetErrorString((hipError_t)e), lds);
   return 0;
@@ -613,13 +614,12 @@ static int launch_integ(odevio_plan* p, IntegArgs& a, int rt, size_t lds, hipStr
 static int run_sequence(odevio_plan* p, const float* fused, const float* ts, const float* hc, int B, int P,
                         float* out_seq, float* hT, int32_t* stats, hipStream_t st) {
   const int L = p->cfg.rnn_num_layers;
-  const int bph_max = 8 / L;  // rows per half <= 8
-  const int slots = INTEG_GROUPS * INTEG_HALVES;
-  const int chunk = slots * bph_max;
+  const int bpg_max = 8 / L;  // rows per group <= 8
+  const int chunk = INTEG_GROUPS * bpg_max;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = std::min(chunk, B - b0);
-    const int BPH = (nb + slots - 1) / slots;
-    const int R = L * BPH;
+    const int BPG = (nb + INTEG_GROUPS - 1) / INTEG_GROUPS;
+    const int R = L * BPG;
     const int rt = R <= 2 ? 2 : (R <= 4 ? 4 : 8);
     IntegArgs a;
     size_t lds;
@@ -627,7 +627,7 @@ static int run_sequence(odevio_plan* p, const float* fused, const float* ts, con
     if (rc) return rc;
     a.mode = p->cfg.model_type == ODEVIO_MODEL_RNN ? MODE_RNN_ONLY : MODE_ODE_RNN;
     a.B = B; a.P = P; a.b_begin = b0; a.b_end = b0 + nb;
-    a.BPH = BPH; a.G = (nb + INTEG_HALVES * BPH - 1) / (INTEG_HALVES * BPH); a.rows_per_half = R;
+    a.BPG = BPG; a.G = (nb + BPG - 1) / BPG; a.rows_per_group = R;
     a.fused = fused; a.ts = ts; a.ts_relative = hc ? 0 : 1; a.hc = hc; a.out_seq = out_seq; a.hT = hT; a.stats = stats;
     if ((rc = launch_integ(p, a, rt, lds, st))) return rc;
   }
@@ -637,19 +637,18 @@ static int run_sequence(odevio_plan* p, const float* fused, const float* ts, con
 static int run_rows(odevio_plan* p, int mode, const float* y, const float* t0, const float* t1, int rows, int solver,
                     int substeps, float* y_out, int32_t* stats, hipStream_t st) {
   if (p->cfg.model_type != ODEVIO_MODEL_ODE_RNN) return fail(ODEVIO_ERR_UNSUPPORTED, "plan has no ODEFunc");
-  const int slots = INTEG_GROUPS * INTEG_HALVES;
-  const int chunk = slots * 8;
+  const int chunk = INTEG_GROUPS * 8;
   for (int r0 = 0; r0 < rows; r0 += chunk) {
     const int nr = std::min(chunk, rows - r0);
-    const int BPH = (nr + slots - 1) / slots;
-    const int rt = BPH <= 2 ? 2 : (BPH <= 4 ? 4 : 8);
+    const int BPG = (nr + INTEG_GROUPS - 1) / INTEG_GROUPS;
+    const int rt = BPG <= 2 ? 2 : (BPG <= 4 ? 4 : 8);
     IntegArgs a;
     size_t lds;
     int rc = integ_common(p, a, rt, solver, substeps, &lds);
     if (rc) return rc;
     a.mode = mode;
     a.B = rows; a.P = 1; a.b_begin = r0; a.b_end = r0 + nr;
-    a.BPH = BPH; a.G = (nr + INTEG_HALVES * BPH - 1) / (INTEG_HALVES * BPH); a.rows_per_half = BPH;
+    a.BPG = BPG; a.G = (nr + BPG - 1) / BPG; a.rows_per_group = BPG;
     a.y0 = y; a.t0 = t0; a.t1 = t1; a.y_out = y_out; a.stats = stats;
     if ((rc = launch_integ(p, a, rt, lds, st))) return rc;
   }

@@ -6,10 +6,8 @@
 #define INTEG_MAX_L 4      // RNN layers
 #define INTEG_MEMBERS 32   // workgroups (CUs) per row group = one XCD under round-robin dispatch
 #define INTEG_GROUPS 8
-#ifndef INTEG_HALVES
-#define INTEG_HALVES 1     // independent row sets a workgroup alternates between (2 = latency-hiding experiment)
-#endif
 #define INTEG_KMAX 1024    // widest vector exchanged between layers
+#define INTEG_THREADS 1024 // 16 waves per workgroup = 4 per SIMD: latency hiding for the dependent layer chain
 
 enum IntegMode { MODE_ODE_RNN = 0, MODE_RNN_ONLY = 1, MODE_ODE_STEPS = 2, MODE_FEVAL = 3 };
 
@@ -28,14 +26,12 @@ struct IntegArgs {
   // ---- vector field  f(y) = tanh(W_n act(... act(W_1 y + b_1)) + b_n)
   int F, H, nlin, act;
   int dims[INTEG_MAX_LIN + 1];            // F, H, ..., H, F
-  const float* w[INTEG_MAX_LIN];          // per-member slices, layout [member][j][col][ks][4]
+  const float* w[INTEG_MAX_LIN];          // per-member slices [member][chunk j][col][lane 0..63][4], K padded to 256
   const float* b[INTEG_MAX_LIN];          // full bias vectors
-  int w_lds_off[INTEG_MAX_LIN];           // float offset of the LDS-resident copy, or -1 = not in LDS
-  int shape_id;                           // 1: F=768, H=512, 4 Linears (statically unrolled layer products); 0: generic
-  int w_reg_layer;                        // layer whose slice lives in registers for the whole launch, or -1
+  int w_lds_off[INTEG_MAX_LIN];           // float offset of the LDS-resident copy, or -1 = stream from L2
   // ---- RNN stack
   int rnn_type, L, rnn_vcols;             // virtual columns per hidden unit: 1 (tanh RNN) or 4 (GRU: r, z, n_i, n_h)
-  const float* rw[INTEG_MAX_L];           // [member][j][col][ks][4], K = 2F ([input | hidden])
+  const float* rw[INTEG_MAX_L];           // same layout, K = [input (F padded) | hidden (F padded)]
   const float* rb[INTEG_MAX_L];           // [vcols][F] folded biases
   // ---- solver
   IntegTableau tab;
@@ -46,8 +42,8 @@ struct IntegArgs {
   int mode;
   int B, P;                               // batch (tensor stride), intervals (timestamps per row = P + 1)
   int b_begin, b_end;                     // batch elements (sequence modes) or rows (row modes) of THIS launch
-  int G, BPH;                             // active groups; sequences (sequence modes) or rows (row modes) per HALF
-  int rows_per_half;                      // L*BPH (sequence modes) or BPH (row modes)
+  int G, BPG;                             // active groups; sequences (sequence modes) or rows (row modes) per group
+  int rows_per_group;                     // L*BPG (sequence modes) or BPG (row modes)
   const float* fused;                     // [B][P][F]
   const float* ts;                        // [B][P+1]
   int ts_relative;                        // 1: subtract ts[:,0] (hc == NULL), reference PoseODERNN.py:100
@@ -60,14 +56,13 @@ struct IntegArgs {
   float* y_out;                           // [rows][F]
   int* stats;                             // [rows][2] or null
   // ---- infrastructure
-  unsigned long long* xbuf;               // [G][halves][2][xstride] 8-byte {tag, value} granules
+  unsigned long long* xbuf;               // [G][2][xstride] 8-byte {tag, value} granules
   int xstride;
   int* status;                            // device status word (0 = ok)
   int allow_local;                        // 1: groups that prove to sit on one XCD use the L2-local hand-off
   unsigned long long* dbg;                // phase stamps (only written by the ODEVIO_STAMPS diagnostic build)
   // ---- LDS carve (float offsets)
-  int lds_half0, lds_half_stride;         // per-half block: xin at +0, hst at +lds_hst, misc at +lds_misc
-  int lds_hst, lds_misc, lds_bias, lds_w;
+  int lds_xin, lds_hst, lds_misc, lds_w;
 };
 
 int launch_integrator(const IntegArgs& a, int rt, size_t lds_bytes, void* stream);

@@ -12,7 +12,7 @@
 //    GROUPS; a group is 32 workgroups = one XCD under the observed round-robin dispatch
 //    (blockIdx & 7; speed only - correctness never depends on placement, see hand-off below);
 //  * inside a group the MLP is COLUMN-sharded: member c owns N/32 output columns of every layer
-//    and keeps its slice of the weights resident in LDS for the whole launch (one slice that does
+//    and keeps its slice of the weights resident in LDS for the whole launch (a slice that does
 //    not fit streams from L2), so the 5.25 MB of ODEFunc parameters are read from HBM once per
 //    launch instead of once per stage;
 //  * between layers the members all-gather the [rows, N] activations through global memory with
@@ -22,23 +22,34 @@
 //    exchange parity: a member can only write exchange e+2 after it has read all of e+1, which
 //    needs every member to have finished reading e, so a buffer is never overwritten while in use.
 //    Every poll is bounded (2 s wall clock) and gives up with ODEVIO_ERR_TIMEOUT in the status word.
+//    Groups that PROVE at run time (HW_REG_XCC_ID census through the safe protocol) that all 32
+//    members share one XCD switch to plain stores that stay in that XCD's L2.
 //  * per-row solver state (t, dt, accept, ...) is computed redundantly by every member from the
 //    same gathered numbers in the same order, so all members take identical control flow.
 //
-// Thread map (256 threads): ks = tid & 15 is a K-slice during a layer product and the ROW a thread
-// owns afterwards; slot = tid >> 4 is a column slot.  State element (row, local col) lives on the
-// thread (ks = row, slot = col % 16) in register col / 16.
+// Thread map: 1024 threads = 16 waves = 4 waves per SIMD.  With one wave per SIMD a layer product cost
+// ~2300 cycles for ~60 instructions of arithmetic (every dependent instruction and LDS read paid its
+// full latency); four co-resident waves hide it.
+//  * layer product:  wave w = column slot (local columns w and w+16), lane = K-slice: lane l multiplies
+//    inputs 256j+4l .. 256j+4l+3 of every 256-wide chunk j, so a wave's 16-byte loads are one contiguous
+//    1 KB run for weights and activations alike; a 64-lane transposing reduction leaves row r's total on
+//    lane r, which drops it into LDS;
+//  * everything per element (bias, activation, publish, Runge-Kutta arithmetic, controller) runs on the
+//    OWNER thread of that element only: element (row r, local column cl) lives on thread cl*RT + r
+//    (at most 256 threads = waves 0..3), so the other twelve waves skip it instead of repeating it.
 #include <type_traits>
 
 #include "common.h"
 #include "integrator.h"
 
 typedef unsigned long long u64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RLX __ATOMIC_RELAXED
 #define AGENT __HIP_MEMORY_SCOPE_AGENT
 #define ST_TIMEOUT (-6)
 #define ST_MAX_STEPS (-7)
 #define SPIN_TIMEOUT_TICKS 200000000ull  // 2 s of the 100 MHz s_memrealtime clock
+#define NT INTEG_THREADS
 
 #ifdef ODEVIO_STAMPS
 #define STAMP_NOW() __builtin_amdgcn_s_memtime()
@@ -50,12 +61,17 @@ typedef unsigned long long u64;
 
 struct Ctx {
   unsigned long long t_gather, t_layer, t_rnn, n_gather;
-  int tid, ks, slot, cu;
+  int tid, lane, wave, cu;
   unsigned epoch;
-  bool local;  // all members of this group share one XCD (verified, not assumed)
+  bool local;   // all members of this group share one XCD (verified, not assumed)
+  u64* xb;      // granule buffers: parity 0 at xb, parity 1 at xb + xstride.  Keep ONE pointer: LLVM turns a
+  int xstride;  // select between two adjacent pointer fields into a runtime-indexed load, which pushes the whole
+                // struct to scratch (and every poll becomes a flat_load).
   int* status;
   bool failed;
 };
+
+__device__ __forceinline__ u64* buf_of(const Ctx& c, unsigned epoch) { return c.xb + ((epoch & 1u) ? c.xstride : 0); }
 
 // One granule = one naturally aligned 8-byte {tag, value} store: the data is its own flag.
 //  * safe form (any placement): relaxed AGENT-scope store = write-through `sc1`, polled with `sc1` loads;
@@ -73,28 +89,44 @@ __device__ __forceinline__ unsigned xcc_id() {
   return v & 0xfu;
 }
 
-// Collect n granules of the current exchange into LDS dst[0..n).  Workgroup-uniform result.
+// Collect the n = rows*width granules of exchange `tag` into LDS: value (row, col) goes to dst[row*ld + col];
+// columns width..ld-1 of every row are zero-filled (K is padded to the 256-wide chunks of the layer product).
+// Workgroup-uniform outcome.
 template <int MAXG>
-__device__ __forceinline__ void gather(Ctx& c, const u64* buf, unsigned tag, int n, float* dst) {
+__device__ __forceinline__ void gather(Ctx& c, const u64* buf, unsigned tag, int rows, int width, int ld, float* dst) {
   const unsigned long long st0 = STAMP_NOW();
   __syncthreads();  // every wave is done reading dst's previous contents
   bool fail = false;
+  const int n = rows * width;
+  if (ld > width) {
+    const int pad = ld - width;
+    for (int i = c.tid; i < rows * pad; i += NT) {
+      const int r = i / pad;
+      dst[r * ld + width + (i - r * pad)] = 0.f;
+    }
+  }
   if (!c.failed) {
     u64 g[MAXG];
     unsigned pend = 0;
 #pragma unroll
     for (int j = 0; j < MAXG; ++j)
-      if (c.tid + 256 * j < n) pend |= 1u << j;
+      if (c.tid + NT * j < n) pend |= 1u << j;
     unsigned spins = 0;
     u64 t_start = 0;
     while (pend) {
 #pragma unroll
       for (int j = 0; j < MAXG; ++j)
-        if ((pend >> j) & 1u) g[j] = __hip_atomic_load(buf + c.tid + 256 * j, RLX, AGENT);
+        if ((pend >> j) & 1u) g[j] = __hip_atomic_load(buf + c.tid + NT * j, RLX, AGENT);
 #pragma unroll
       for (int j = 0; j < MAXG; ++j)
         if (((pend >> j) & 1u) && (unsigned)(g[j] >> 32) == tag) {
-          dst[c.tid + 256 * j] = __uint_as_float((unsigned)g[j]);
+          const int idx = c.tid + NT * j;
+          int o = idx;
+          if (ld != width) {
+            const int r = idx / width;
+            o = r * ld + (idx - r * width);
+          }
+          dst[o] = __uint_as_float((unsigned)g[j]);
           pend &= ~(1u << j);
         }
       if (pend) {
@@ -116,28 +148,21 @@ __device__ __forceinline__ void gather(Ctx& c, const u64* buf, unsigned tag, int
   c.n_gather += 1;
 }
 
-__device__ __forceinline__ float dot4(const f32x4 w, const f32x4 x, float acc) {
-  acc = fmaf(w[0], x[0], acc);
-  acc = fmaf(w[1], x[1], acc);
-  acc = fmaf(w[2], x[2], acc);
-  acc = fmaf(w[3], x[3], acc);
-  return acc;
-}
-
-// ---- transposing reduction over the 16 lanes of a DPP row (one column slot's K-slices) ---------------------
-// Every lane enters with RT partial sums (one per row) and leaves with the TOTAL of row (ks mod RT): at each of
-// the first log2(RT) levels a lane keeps the half of its rows selected by one bit of ks and adds the partner's
-// partials for those rows, so the row index is assembled from the lane's own ks bits and no lane ever holds
-// (or selects from) all rows' totals.  xor-1 / xor-2 partners are DPP quad_perms; the remaining lanes that
-// hold the same row are folded with row_ror (a rotate by 8 then 4 visits lanes i, i+4, i+8, i+12).
+// ---- transposing reduction over the 64 lanes of a wave ----------------------------------------------
+// Every lane enters with RT partial sums (one per row) and leaves with the TOTAL of row (lane mod RT): at each of
+// the first log2(RT) levels a lane keeps the half of its rows selected by one bit of its lane id and adds the
+// partner's partials for those rows, so no lane ever holds (or selects from) all rows' totals.  lane^1 / lane^2
+// partners are DPP quad_perms, lane^4 a ds_swizzle (crossbar only); the remaining lanes that hold the same row are
+// folded with row_ror (rotate by 8 then 4 visits lanes i, i+4, i+8, i+12 of a 16-lane row), a swizzle (lane^16)
+// and one ds_bpermute (lane^32).
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 template <int RT>
-__device__ __forceinline__ float reduce_rows(const float (&v)[RT], int ks) {
-  static_assert(RT == 2 || RT == 4 || RT == 8, "rows per half");
-  const bool b0 = ks & 1, b1 = ks & 2, b2 = ks & 4;
+__device__ __forceinline__ float reduce_rows64(const float (&v)[RT], int lane) {
+  static_assert(RT == 2 || RT == 4 || RT == 8, "rows per group");
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
   float a[RT / 2];
 #pragma unroll
   for (int i = 0; i < RT / 2; ++i) {
@@ -148,9 +173,9 @@ __device__ __forceinline__ float reduce_rows(const float (&v)[RT], int ks) {
   float d;
   if (RT == 2) {
     d = a[0];
-    d += dpp_mov<0x4E>(d);  // lanes with the same ks&1: ^2, then +8, +4
-    d += dpp_mov<0x128>(d);
-    d += dpp_mov<0x124>(d);
+    d += dpp_mov<0x4E>(d);   // lane ^ 2
+    d += dpp_mov<0x128>(d);  // row_ror:8
+    d += dpp_mov<0x124>(d);  // row_ror:4
   } else {
     float c[RT / 4 > 0 ? RT / 4 : 1];
 #pragma unroll
@@ -162,8 +187,7 @@ __device__ __forceinline__ float reduce_rows(const float (&v)[RT], int ks) {
     if (RT == 8) {
       const float keep = b2 ? c[RT / 4 - 1] : c[0];
       const float send = b2 ? c[0] : c[RT / 4 - 1];
-      // lane ^ 4 has no DPP form: ds_swizzle bit-mask mode (and 0x1f, or 0, xor 4) - crossbar only, no LDS memory
-      d = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), 0x101F));
+      d = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), 0x101F));  // lane ^ 4
       d += dpp_mov<0x128>(d);  // row_ror:8
     } else {
       d = c[0];
@@ -171,84 +195,30 @@ __device__ __forceinline__ float reduce_rows(const float (&v)[RT], int ks) {
       d += dpp_mov<0x124>(d);  // row_ror:4
     }
   }
+  d += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(d), 0x401F));  // lane ^ 16 (and 0x1f, xor 0x10)
+  d += __shfl_xor(d, 32, 64);                                                    // lane ^ 32
   return d;
 }
 
-// K-segment of a layer product: nseg chunks of 64 inputs starting at weight chunk jbase, inputs from xs (row
-// stride ld).  Software-pipelined by hand (hipcc issues a load right before its use otherwise, exposing the full
-// L2 / LDS latency every chunk): weight chunks run WD iterations ahead in a register ring, the activations one
-// chunk ahead.  Partial sums are kept as (even k, odd k) pairs so that each multiply-add is one v_pk_fma_f32 on
-// register pairs that the 16-byte loads already deliver adjacent.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#define LAYER_WD 4
-
+// One wave's share of a layer product: acc[c][r] += sum over this lane's K-slice of W[col_c][k] * x[r][k] for
+// nseg 256-wide chunks starting at weight chunk jbase; row r's inputs start at xs + roff[r].
+// Partial sums are (even k, odd k) pairs so that each multiply-add is one v_pk_fma_f32 on register pairs that the
+// 16-byte loads deliver adjacent.
 template <int RT, bool TWO>
-__device__ __forceinline__ void layer_seg(const float* __restrict__ wbase, int NC, int jbase, int nseg,
-                                          const float* xs, const int (&roff)[RT], int c0, int c1, int ks,
-                                          f32x2 (&acc)[2][RT]) {
-  const float* w0p = wbase + (((size_t)jbase * NC + c0) * 16 + ks) * 4;
-  const float* w1p = wbase + (((size_t)jbase * NC + c1) * 16 + ks) * 4;
-  const size_t wstep = (size_t)NC * 64;
-  xs += 4 * ks;
-  f32x4 wq0[LAYER_WD], wq1[LAYER_WD];
-#pragma unroll
-  for (int d = 0; d < LAYER_WD; ++d) {
-    const int jj = d < nseg ? d : nseg - 1;
-    wq0[d] = *reinterpret_cast<const f32x4*>(w0p + jj * wstep);
-    if (TWO) wq1[d] = *reinterpret_cast<const f32x4*>(w1p + jj * wstep);
-  }
-  f32x4 xc[RT];
-#pragma unroll
-  for (int r = 0; r < RT; ++r) xc[r] = *reinterpret_cast<const f32x4*>(xs + roff[r]);
-  for (int j0 = 0; j0 < nseg; j0 += LAYER_WD) {
-#pragma unroll
-    for (int d = 0; d < LAYER_WD; ++d) {
-      const int j = j0 + d;
-      if (j < nseg) {
-        const f32x4 w0 = wq0[d];
-        f32x4 w1 = w0;
-        if (TWO) w1 = wq1[d];
-        const int jn = j + LAYER_WD < nseg ? j + LAYER_WD : nseg - 1;  // refill this ring slot (clamped: harmless re-read)
-        wq0[d] = *reinterpret_cast<const f32x4*>(w0p + jn * wstep);
-        if (TWO) wq1[d] = *reinterpret_cast<const f32x4*>(w1p + jn * wstep);
-        f32x4 xn[RT];
-        const int jx = j + 1 < nseg ? j + 1 : j;
-#pragma unroll
-        for (int r = 0; r < RT; ++r) xn[r] = *reinterpret_cast<const f32x4*>(xs + jx * 64 + roff[r]);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          acc[0][r] = __builtin_elementwise_fma(w0.lo, xc[r].lo, acc[0][r]);
-          acc[0][r] = __builtin_elementwise_fma(w0.hi, xc[r].hi, acc[0][r]);
-          if (TWO) {
-            acc[1][r] = __builtin_elementwise_fma(w1.lo, xc[r].lo, acc[1][r]);
-            acc[1][r] = __builtin_elementwise_fma(w1.hi, xc[r].hi, acc[1][r]);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < RT; ++r) xc[r] = xn[r];
-      }
-    }
-  }
-}
-
-// Fully static form for a known layer shape (NSEG chunks, NCT columns per member): straight-line code, every
-// LDS / L2 address is a lane base plus an immediate, no loop control and no guards - at one wave per SIMD the
-// instruction count IS the latency, and the generic ring above spends ~5x more instructions than arithmetic.
-template <int RT, bool TWO, int NSEG, int NCT>
-__device__ __forceinline__ void layer_seg_static(const float* __restrict__ wbase, int jbase, const float* xs,
-                                                 const int (&roff)[RT], int c0, int c1, int ks,
-                                                 f32x2 (&acc)[2][RT]) {
-  const float* w0p = wbase + (((size_t)jbase * NCT + c0) * 16 + ks) * 4;
-  const float* w1p = wbase + (((size_t)jbase * NCT + c1) * 16 + ks) * 4;
-  xs += 4 * ks;
-#pragma unroll
-  for (int j = 0; j < NSEG; ++j) {
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w0p + j * NCT * 64);
+__device__ __forceinline__ void layer_seg(const float* __restrict__ wbase, int NC, int jbase, int nseg, const float* xs,
+                                          const int (&roff)[RT], int c0, int c1, int lane, f32x2 (&acc)[2][RT]) {
+  const float* w0p = wbase + (((size_t)jbase * NC + c0) * 64 + lane) * 4;
+  const float* w1p = wbase + (((size_t)jbase * NC + c1) * 64 + lane) * 4;
+  const size_t wstep = (size_t)NC * 256;
+  xs += 4 * lane;
+#pragma unroll 2
+  for (int j = 0; j < nseg; ++j) {
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w0p + j * wstep);
     f32x4 w1 = w0;
-    if (TWO) w1 = *reinterpret_cast<const f32x4*>(w1p + j * NCT * 64);
+    if (TWO) w1 = *reinterpret_cast<const f32x4*>(w1p + j * wstep);
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(xs + j * 64 + roff[r]);
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xs + j * 256 + roff[r]);
       acc[0][r] = __builtin_elementwise_fma(w0.lo, x.lo, acc[0][r]);
       acc[0][r] = __builtin_elementwise_fma(w0.hi, x.hi, acc[0][r]);
       if (TWO) {
@@ -259,91 +229,41 @@ __device__ __forceinline__ void layer_seg_static(const float* __restrict__ wbase
   }
 }
 
-// The same product with this thread's weights already in registers (one column, <= LAYER_REG_NJ chunks): the
-// one ODEFunc slice that does not fit in LDS beside the others is loaded ONCE per launch instead of being
-// streamed from L2 at every stage (an L2 round trip per chunk is ~1 us of exposed latency per evaluation).
-#define LAYER_REG_NJ 16
+// Layer product for local columns col0 = pass*32 + wave and col0 + 16 (where < NC): row r reads its first K1p
+// inputs at xa + offa[r] and the remaining K2p at xb + offb[r] (both padded to multiples of 256).  The totals
+// of rows 0..RT-1 land on lanes 0..RT-1, which store them to out[col * RT + row].
 template <int RT>
-__device__ __forceinline__ void layer_seg_reg(const f32x4 (&wr)[LAYER_REG_NJ], int nseg, const float* xs,
-                                              const int (&roff)[RT], int ks, f32x2 (&acc)[2][RT]) {
-  xs += 4 * ks;
-#pragma unroll
-  for (int j = 0; j < LAYER_REG_NJ; ++j) {
-    if (j < nseg) {
-#pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(xs + j * 64 + roff[r]);
-        acc[0][r] = __builtin_elementwise_fma(wr[j].lo, x.lo, acc[0][r]);
-        acc[0][r] = __builtin_elementwise_fma(wr[j].hi, x.hi, acc[0][r]);
-      }
-    }
-  }
-}
-
-// One layer product for this member: acc[c][r] = sum_k W[col_c][k] * x[r][k], c = 0,1 (local columns
-// col0 = pass*32 + slot and col0 + 16), r < RT.  Row r reads its first K1 inputs at xa + offa[r] and the
-// remaining K2 at xb + offb[r].  wr != nullptr selects the register-resident weights (K2 == 0, one column).
-// On return res[c] is the total of row (ks mod RT) for column c (reduce_rows).
-template <int RT, int NSEG1 = 0, int NCT = 0>
-__device__ __forceinline__ void layer(const float* __restrict__ wbase, const f32x4 (*wr)[LAYER_REG_NJ], int NC, int K1,
-                                      const float* xa, const int (&offa)[RT], int K2, const float* xb,
-                                      const int (&offb)[RT], int col0, int ks, float (&res)[2]) {
+__device__ __forceinline__ void layer(const float* __restrict__ wbase, int NC, int K1p, const float* xa,
+                                      const int (&offa)[RT], int K2p, const float* xb, const int (&offb)[RT],
+                                      int col0, int lane, float* out) {
+  if (col0 >= NC) return;  // wave-uniform: this wave owns no column of this layer / pass
   f32x2 acc[2][RT];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[c][r] = (f32x2){0.f, 0.f};
-  const int c0 = col0 < NC ? col0 : NC - 1;  // clamp: out-of-range columns compute garbage that is discarded
-  const int c1 = col0 + 16 < NC ? col0 + 16 : c0;
-  // a wave holds 4 consecutive column slots, so "this wave has a second column" is wave-uniform
-  const bool two = __builtin_amdgcn_readfirstlane((int)(((col0 & ~3) + 16) < NC)) != 0;
-  const int nj1 = K1 >> 6, nj2 = K2 >> 6;
-  if (NSEG1 > 0 && !wr) {
-    // static shape (K2 == 0 by construction of the callers)
-    if (two) {
-      layer_seg_static<RT, true, NSEG1, NCT>(wbase, 0, xa, offa, c0, c1, ks, acc);
-      float s0[RT], s1[RT];
-#pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        s0[r] = acc[0][r].x + acc[0][r].y;
-        s1[r] = acc[1][r].x + acc[1][r].y;
-      }
-      res[0] = reduce_rows<RT>(s0, ks);
-      res[1] = reduce_rows<RT>(s1, ks);
-    } else {
-      layer_seg_static<RT, false, NSEG1, NCT>(wbase, 0, xa, offa, c0, c1, ks, acc);
-      float s0[RT];
-#pragma unroll
-      for (int r = 0; r < RT; ++r) s0[r] = acc[0][r].x + acc[0][r].y;
-      res[0] = reduce_rows<RT>(s0, ks);
-      res[1] = 0.f;
-    }
-  } else if (wr) {
-    layer_seg_reg<RT>(*wr, nj1, xa, offa, ks, acc);
-    float s0[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) s0[r] = acc[0][r].x + acc[0][r].y;
-    res[0] = reduce_rows<RT>(s0, ks);
-    res[1] = 0.f;
-  } else if (two) {
-    layer_seg<RT, true>(wbase, NC, 0, nj1, xa, offa, c0, c1, ks, acc);
-    if (nj2) layer_seg<RT, true>(wbase, NC, nj1, nj2, xb, offb, c0, c1, ks, acc);
-    float s0[RT], s1[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      s0[r] = acc[0][r].x + acc[0][r].y;
-      s1[r] = acc[1][r].x + acc[1][r].y;
-    }
-    res[0] = reduce_rows<RT>(s0, ks);
-    res[1] = reduce_rows<RT>(s1, ks);
+  const int c0 = col0;
+  const bool two = col0 + 16 < NC;  // wave-uniform
+  const int c1 = two ? col0 + 16 : c0;
+  const int nj1 = K1p >> 8, nj2 = K2p >> 8;
+  float s0[RT], s1[RT];
+  if (two) {
+    layer_seg<RT, true>(wbase, NC, 0, nj1, xa, offa, c0, c1, lane, acc);
+    if (nj2) layer_seg<RT, true>(wbase, NC, nj1, nj2, xb, offb, c0, c1, lane, acc);
   } else {
-    layer_seg<RT, false>(wbase, NC, 0, nj1, xa, offa, c0, c1, ks, acc);
-    if (nj2) layer_seg<RT, false>(wbase, NC, nj1, nj2, xb, offb, c0, c1, ks, acc);
-    float s0[RT];
+    layer_seg<RT, false>(wbase, NC, 0, nj1, xa, offa, c0, c1, lane, acc);
+    if (nj2) layer_seg<RT, false>(wbase, NC, nj1, nj2, xb, offb, c0, c1, lane, acc);
+  }
 #pragma unroll
-    for (int r = 0; r < RT; ++r) s0[r] = acc[0][r].x + acc[0][r].y;
-    res[0] = reduce_rows<RT>(s0, ks);
-    res[1] = 0.f;
+  for (int r = 0; r < RT; ++r) {
+    s0[r] = acc[0][r].x + acc[0][r].y;
+    s1[r] = acc[1][r].x + acc[1][r].y;
+  }
+  const float t0 = reduce_rows64<RT>(s0, lane);
+  if (lane < RT) out[c0 * RT + lane] = t0;
+  if (two) {
+    const float t1 = reduce_rows64<RT>(s1, lane);
+    if (lane < RT) out[c1 * RT + lane] = t1;
   }
 }
 
@@ -358,43 +278,16 @@ __device__ __forceinline__ float hidden_act(float v, int act) {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-
-// ================================================================================================
-// The kernel.  Each workgroup serves INTEG_HALVES independent row sets ("halves") of its group in
-// strict alternation: while half A's activations are in flight to the other members, the workgroup
-// computes half B's layer, so the hand-off latency of one half hides under the arithmetic of the
-// other.  The halves never exchange data (rows are independent), own separate granule buffers and
-// advance through the same sequence of exchanges, so one epoch counter serves both.
-// ================================================================================================
-template <int RT>
-struct Half {
-  u64* xb;   // granule buffers: parity 0 at xb, parity 1 at xb + xstride.  Keep ONE pointer: LLVM turns a select
-  int xstride;  // between two adjacent pointer fields into a runtime-indexed load, which pushes the whole struct
-                // to scratch (and every poll becomes a flat_load).
-  float *xin, *hst, *red, *nrm, *mv, *pre;
-  bool active;     // this half has at least one real row (workgroup-uniform)
-  bool has_row;    // this thread's ks addresses a row slot of the half
-  bool row_valid;  // ... and that slot holds a real sequence / row
-  int row_l, row_b, grow;
-  float y[2];
-  float k[7][2];
-  float t, t1, dt, dtn;
-  bool last, running;
-  int sub_left, n_steps, n_acc;
-};
+__device__ __forceinline__ int pad256(int k) { return (k + 255) & ~255; }
 
 template <int RT>
-__device__ __forceinline__ u64* buf_of(const Half<RT>& h, unsigned epoch) { return h.xb + ((epoch & 1u) ? h.xstride : 0); }
-
-template <int RT>
-__global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
+__global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int MAXG = (RT * INTEG_KMAX + 255) / 256;
-  constexpr int NH = INTEG_HALVES;
+  constexpr int MAXG = (RT * INTEG_KMAX + NT - 1) / NT;
   Ctx c;
   c.tid = threadIdx.x;
-  c.ks = c.tid & 15;
-  c.slot = c.tid >> 4;
+  c.lane = c.tid & 63;
+  c.wave = c.tid >> 6;
   const int g = blockIdx.x & (INTEG_GROUPS - 1);
   c.cu = blockIdx.x >> 3;
   if (g >= a.G) return;
@@ -402,71 +295,48 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   c.status = a.status;
   c.failed = false;
   c.local = false;
+  c.xb = a.xbuf + (size_t)(2 * g) * a.xstride;
+  c.xstride = a.xstride;
   c.t_gather = c.t_layer = c.t_rnn = c.n_gather = 0;
   const unsigned long long t_begin = STAMP_NOW();
-  const int tid = c.tid, ks = c.ks, slot = c.slot, cu = c.cu;
+  const int tid = c.tid, lane = c.lane, wave = c.wave, cu = c.cu;
 
-  const bool seq_mode = (a.mode == MODE_ODE_RNN || a.mode == MODE_RNN_ONLY);
-  const int F = a.F;
-  const int NCF = F / INTEG_MEMBERS;
-  const int R = a.rows_per_half;
-  const int BPH = a.BPH;
-  float* bia = smem + a.lds_bias;  // [INTEG_MAX_LIN][32] this member's ODEFunc biases
+  float* xin = smem + a.lds_xin;    // [RT][KMAXp]   gathered layer input
+  float* hst = smem + a.lds_hst;    // [RT][Fp]      gathered evolved state (RNN phase)
+  float* lay = smem + a.lds_misc;   // [128][RT]     layer-product totals, out[col*RT + row]
+  float* nrm = lay + 128 * RT;      // [RT][32]      per-member error-norm partials
+  float* mv = nrm + RT * 32;        // [RT][32]      new hidden state on its way to the owner threads
+  float* qb = mv + RT * 32;         // [256]         per-element error quotients
+  float* bia = qb + 256;            // [INTEG_MAX_LIN][32] this member's ODEFunc biases
   float* wl = smem + a.lds_w;
 
-  Half<RT> hs[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    Half<RT>& H = hs[h];
-    H.xb = a.xbuf + (size_t)((g * NH + h) * 2) * a.xstride;
-    H.xstride = a.xstride;
-    float* base = smem + a.lds_half0 + h * a.lds_half_stride;
-    H.xin = base;
-    H.hst = base + a.lds_hst;
-    H.red = base + a.lds_misc;     // [4][16]
-    H.nrm = H.red + 64;            // [RT][32]
-    H.mv = H.nrm + RT * 32;        // [RT][32]
-    H.pre = H.mv + RT * 32;        // [4*32][RT]
-    const int first = a.b_begin + (g * NH + h) * BPH;  // first sequence (or row) of this half
-    H.active = first < a.b_end;
-    H.has_row = ks < R;
-    H.row_l = 0;
-    H.row_b = 0;
-    H.grow = 0;
-    H.row_valid = false;
-    if (H.has_row) {
-      if (seq_mode) {
-        H.row_l = ks / BPH;
-        H.row_b = first + (ks - H.row_l * BPH);
-        H.row_valid = H.row_b < a.b_end;
-        H.grow = H.row_l * a.B + H.row_b;
-      } else {
-        H.grow = first + ks;
-        H.row_valid = H.grow < a.b_end;
-      }
-    }
-    H.y[0] = H.y[1] = 0.f;
-    H.n_steps = H.n_acc = 0;
-  }
+  const bool seq_mode = (a.mode == MODE_ODE_RNN || a.mode == MODE_RNN_ONLY);
+  const int F = a.F, Fp = pad256(F);
+  const int NCF = F / INTEG_MEMBERS;
+  const int R = a.rows_per_group;
+  const int BPG = a.BPG;
 
-  // this thread's columns of an F-wide vector
-  int colg[2];
-  bool colv[2];
-#pragma unroll
-  for (int ci = 0; ci < 2; ++ci) {
-    const int cl = ci * 16 + slot;
-    colv[ci] = cl < NCF;
-    colg[ci] = cu * NCF + (colv[ci] ? cl : 0);
-  }
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    if (!hs[h].row_valid) continue;
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-      if (!colv[ci]) continue;
-      if (seq_mode) hs[h].y[ci] = a.hc ? a.hc[(size_t)hs[h].grow * F + colg[ci]] : 0.f;
-      else hs[h].y[ci] = a.y0[(size_t)hs[h].grow * F + colg[ci]];
+  // ---- owner role: thread t < NCF*RT owns state element (row = t % RT, local column = t / RT)
+  const int orow = tid % RT, ocl = tid / RT;
+  const bool owner = ocl < NCF && orow < R;
+  const int ocg = cu * NCF + (ocl < NCF ? ocl : 0);  // global column of the owned element
+  int row_l = 0, row_b = 0, grow = 0;
+  bool row_valid = false;
+  if (orow < R) {
+    if (seq_mode) {
+      row_l = orow / BPG;
+      row_b = a.b_begin + g * BPG + (orow - row_l * BPG);
+      row_valid = row_b < a.b_end;
+      grow = row_l * a.B + row_b;
+    } else {
+      grow = a.b_begin + g * BPG + orow;
+      row_valid = grow < a.b_end;
     }
+  }
+  float y = 0.f;
+  if (owner && row_valid) {
+    if (seq_mode) y = a.hc ? a.hc[(size_t)grow * F + ocg] : 0.f;
+    else y = a.y0[(size_t)grow * F + ocg];
   }
 
   // ---- placement census: the members tell each other their XCD through the SAFE protocol; only if all 32
@@ -474,16 +344,16 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   if (a.allow_local) {
     ++c.epoch;
     const unsigned mine = xcc_id();
-    if (tid == 0) put(buf_of(hs[0], c.epoch) + cu, __uint_as_float(mine + 1u), c.epoch, false);
-    gather<MAXG>(c, buf_of(hs[0], c.epoch), c.epoch, INTEG_MEMBERS, hs[0].nrm);
+    if (tid == 0) put(buf_of(c, c.epoch) + cu, __uint_as_float(mine + 1u), c.epoch, false);
+    gather<MAXG>(c, buf_of(c, c.epoch), c.epoch, 1, INTEG_MEMBERS, INTEG_MEMBERS, nrm);
     bool same = true;
-    for (int m = 0; m < INTEG_MEMBERS; ++m) same = same && (__float_as_uint(hs[0].nrm[m]) == mine + 1u);
+    for (int m = 0; m < INTEG_MEMBERS; ++m) same = same && (__float_as_uint(nrm[m]) == mine + 1u);
     c.local = same && !c.failed;
     __syncthreads();
   }
   if (a.dbg && cu == 0 && tid == 0) reinterpret_cast<unsigned char*>(a.dbg + 5)[g] = c.local ? 1 : 0;  // byte per group
 
-  for (int i = tid; i < a.nlin * 32; i += 256) {
+  for (int i = tid; i < a.nlin * 32; i += NT) {
     const int l = i >> 5, cl = i & 31;
     const int NC = a.dims[l + 1] / INTEG_MEMBERS;
     bia[i] = cl < NC ? a.b[l][cu * NC + cl] : 0.f;
@@ -491,106 +361,50 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   // ---- resident weight slices -> LDS (read from HBM once per launch)
   for (int l = 0; l < a.nlin; ++l) {
     if (a.w_lds_off[l] < 0) continue;
-    const int n = (a.dims[l + 1] / INTEG_MEMBERS) * a.dims[l];
+    const int n = (a.dims[l + 1] / INTEG_MEMBERS) * pad256(a.dims[l]);
     const float* src = a.w[l] + (size_t)cu * n;
     float* dstw = wl + a.w_lds_off[l];
-    for (int i = tid * 4; i < n; i += 1024)
+    for (int i = tid * 4; i < n; i += NT * 4)
       *reinterpret_cast<f32x4*>(dstw + i) = *reinterpret_cast<const f32x4*>(src + i);
   }
-  // ---- the slice that does not fit in LDS: this thread's weights of that layer, once, into registers
-  f32x4 wreg[LAYER_REG_NJ];
-#pragma unroll
-  for (int j = 0; j < LAYER_REG_NJ; ++j) wreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (a.w_reg_layer >= 0) {
-    const int l = a.w_reg_layer;
-    const int NC = a.dims[l + 1] / INTEG_MEMBERS, K = a.dims[l];
-    const float* src = a.w[l] + (size_t)cu * NC * K;
-    const int cc = slot < NC ? slot : NC - 1;
-#pragma unroll
-    for (int j = 0; j < LAYER_REG_NJ; ++j)
-      if (j < (K >> 6)) wreg[j] = *reinterpret_cast<const f32x4*>(src + (((size_t)j * NC + cc) * 16 + ks) * 4);
-  }
-  int off_ode[RT];  // row offsets of an ODEFunc layer input [R][K] are set per layer below
   __syncthreads();
 
-  // vector field for both halves: stage values sv[h] (this thread's elements) -> ko[h]
-  auto feval = [&](const float (&sv)[NH][2], float (&ko)[NH][2]) __attribute__((always_inline)) {
+  int off_ode[RT];
+
+  // vector field: the owner threads hand in their stage value sv and get k = f(sv) back
+  auto feval = [&](float sv) __attribute__((always_inline)) -> float {
+    float ko = 0.f;
     ++c.epoch;
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      if (hs[h].active && hs[h].has_row) {
-        u64* buf = buf_of(hs[h], c.epoch);
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-          if (colv[ci]) put(buf + ks * F + colg[ci], sv[h][ci], c.epoch, c.local);
-      }
-    }
-    auto do_layer = [&](auto nseg_c, auto nct_c, int l) __attribute__((always_inline)) {
-      constexpr int NSEG = decltype(nseg_c)::value, NCT = decltype(nct_c)::value;
+    if (owner) put(buf_of(c, c.epoch) + orow * F + ocg, sv, c.epoch, c.local);
+    for (int l = 0; l < a.nlin; ++l) {
       const int K = a.dims[l], N = a.dims[l + 1];
+      const int Kp = pad256(K);
       const int NC = N / INTEG_MEMBERS;
       const bool more = l + 1 < a.nlin;
+      gather<MAXG>(c, buf_of(c, c.epoch), c.epoch, R, K, Kp, xin);
+      const unsigned long long sl0 = STAMP_NOW();
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (!hs[h].active) continue;
-        gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, R * K, hs[h].xin);
-        float res[2];
-        const unsigned long long sl0 = STAMP_NOW();
-#pragma unroll
-        for (int r = 0; r < RT; ++r) off_ode[r] = (r < R ? r : R - 1) * K;
-        if (a.w_lds_off[l] >= 0)
-          layer<RT, NSEG, NCT>(wl + a.w_lds_off[l], nullptr, NC, K, hs[h].xin, off_ode, 0, hs[h].xin, off_ode, slot, ks, res);
-        else if (l == a.w_reg_layer)
-          layer<RT>(nullptr, &wreg, NC, K, hs[h].xin, off_ode, 0, hs[h].xin, off_ode, slot, ks, res);
-        else
-          layer<RT>(a.w[l] + (size_t)cu * NC * K, nullptr, NC, K, hs[h].xin, off_ode, 0, hs[h].xin, off_ode, slot, ks, res);
-        STAMP_ADD(c.t_layer, sl0);
-        float v[2];
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci) v[ci] = res[ci] + bia[l * 32 + ci * 16 + slot];
-        if (more) {
-          if (hs[h].has_row) {
-            u64* buf = buf_of(hs[h], c.epoch + 1);
-#pragma unroll
-            for (int ci = 0; ci < 2; ++ci) {
-              const int cl = ci * 16 + slot;
-              if (cl < NC) put(buf + ks * N + cu * NC + cl, hidden_act(v[ci], a.act), c.epoch + 1, c.local);
-            }
-          }
-        } else {
-          ko[h][0] = tanhf(v[0]);
-          ko[h][1] = tanhf(v[1]);
-        }
+      for (int r = 0; r < RT; ++r) off_ode[r] = (r < R ? r : R - 1) * Kp;
+      if (a.w_lds_off[l] >= 0)
+        layer<RT>(wl + a.w_lds_off[l], NC, Kp, xin, off_ode, 0, xin, off_ode, wave, lane, lay);
+      else
+        layer<RT>(a.w[l] + (size_t)cu * NC * Kp, NC, Kp, xin, off_ode, 0, xin, off_ode, wave, lane, lay);
+      STAMP_ADD(c.t_layer, sl0);
+      __syncthreads();
+      // owners of this layer's outputs: thread t < NC*RT -> (row t % RT, column t / RT)
+      if (ocl < NC && orow < R) {
+        const float v = lay[tid] + bia[l * 32 + ocl];
+        if (more) put(buf_of(c, c.epoch + 1) + orow * N + cu * NC + ocl, hidden_act(v, a.act), c.epoch + 1, c.local);
+        else ko = tanhf(v);
       }
       if (more) ++c.epoch;
-    };
-    using std::integral_constant;
-    if (a.shape_id == 1) {
-      // ODEFunc 768 -> 512 -> 512 -> 512 -> 768 (reference defaults, scripts/config.py:50-51,62-63)
-      do_layer(integral_constant<int, 12>{}, integral_constant<int, 16>{}, 0);
-      do_layer(integral_constant<int, 8>{}, integral_constant<int, 16>{}, 1);
-      do_layer(integral_constant<int, 8>{}, integral_constant<int, 16>{}, 2);
-      do_layer(integral_constant<int, 8>{}, integral_constant<int, 24>{}, 3);
-    } else {
-      for (int l = 0; l < a.nlin; ++l) do_layer(integral_constant<int, 0>{}, integral_constant<int, 0>{}, l);
     }
+    return ko;
   };
 
   if (a.mode == MODE_FEVAL) {
-    float sv[NH][2], kk[NH][2] = {};
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      sv[h][0] = hs[h].y[0];
-      sv[h][1] = hs[h].y[1];
-    }
-    feval(sv, kk);
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      if (!hs[h].row_valid) continue;
-#pragma unroll
-      for (int ci = 0; ci < 2; ++ci)
-        if (colv[ci]) a.y_out[(size_t)hs[h].grow * F + colg[ci]] = kk[h][ci];
-    }
+    const float kk = feval(y);
+    if (owner && row_valid) a.y_out[(size_t)grow * F + ocg] = kk;
     return;
   }
 
@@ -598,192 +412,142 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   const float inv_order = -1.f / (float)a.tab.order;
   const int n_int = seq_mode ? a.P : 1;
   const bool fixed = (a.tab.has_err == 0 && a.nsub > 0);
+  int n_steps = 0, n_acc = 0;
 
   for (int it = 0; it < n_int && !c.failed; ++it) {
     // ======================= ODE phase =======================
     if (a.mode != MODE_RNN_ONLY) {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        Half<RT>& H = hs[h];
-        H.t = 0.f;
-        H.t1 = 0.f;
-        if (H.row_valid) {
-          if (seq_mode) {
-            const float* tr = a.ts + (size_t)H.row_b * (a.P + 1);
-            const float base = a.ts_relative ? tr[0] : 0.f;
-            H.t = tr[it] - base;
-            H.t1 = tr[it + 1] - base;
-          } else {
-            H.t = a.t0[H.grow];
-            H.t1 = a.t1[H.grow];
-          }
-        }
-        H.dtn = a.dt0;
-        H.last = false;
-        H.sub_left = a.nsub;
-        if (fixed) {
-          H.dt = (H.t1 - H.t) / (float)a.nsub;
-          H.running = H.row_valid;
+      float t = 0.f, t1 = 0.f;
+      if (row_valid) {
+        if (seq_mode) {
+          const float* tr = a.ts + (size_t)row_b * (a.P + 1);
+          const float base = a.ts_relative ? tr[0] : 0.f;
+          t = tr[it] - base;
+          t1 = tr[it + 1] - base;
         } else {
-          const float span = H.t1 - H.t;
-          H.last = H.dtn >= span;
-          H.dt = H.last ? span : H.dtn;
-          H.running = H.row_valid && (H.t < H.t1);
+          t = a.t0[grow];
+          t1 = a.t1[grow];
         }
-#pragma unroll
-        for (int j = 0; j < 7; ++j) H.k[j][0] = H.k[j][1] = 0.f;
       }
+      float dt, dtn = a.dt0;
+      bool last = false, running;
+      int sub_left = a.nsub;
+      if (fixed) {
+        dt = (t1 - t) / (float)a.nsub;
+        running = row_valid;
+      } else {
+        const float span = t1 - t;
+        last = dtn >= span;
+        dt = last ? span : dtn;
+        running = row_valid && (t < t1);
+      }
+      float k[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) k[j] = 0.f;
       bool have_k1 = false;
       int guard = 0;
-      while (__syncthreads_or(((hs[0].running && hs[0].has_row) || (hs[NH - 1].running && hs[NH - 1].has_row)) ? 1 : 0)) {
+      while (__syncthreads_or((running && owner) ? 1 : 0)) {
         if (c.failed) break;
         if (++guard > a.max_steps) {
           if (tid == 0) atomicCAS(c.status, 0, ST_MAX_STEPS);
           break;
         }
-        float sv[NH][2];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          sv[h][0] = hs[h].y[0];
-          sv[h][1] = hs[h].y[1];
-        }
+        float sv = y;
         for (int s = 0; s < S; ++s) {
           if (s == 0 && have_k1) continue;
           if (s > 0) {
+            float a0 = 0.f;
+            bool first = true;
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
-              float a0 = 0.f, a1 = 0.f;
-              bool first = true;
-#pragma unroll
-              for (int j = 0; j < 6; ++j) {
-                if (j < s) {
-                  const float co = a.tab.a[s][j];
-                  if (co != 0.f) {
-                    // same association as the oracle: acc = k_j*a_sj summed left to right
-                    a0 = first ? hs[h].k[j][0] * co : a0 + hs[h].k[j][0] * co;
-                    a1 = first ? hs[h].k[j][1] * co : a1 + hs[h].k[j][1] * co;
-                    first = false;
-                  }
+            for (int j = 0; j < 6; ++j) {
+              if (j < s) {
+                const float co = a.tab.a[s][j];
+                if (co != 0.f) {
+                  a0 = first ? k[j] * co : a0 + k[j] * co;  // same association as the oracle
+                  first = false;
                 }
               }
-              sv[h][0] = hs[h].y[0] + hs[h].dt * a0;
-              sv[h][1] = hs[h].y[1] + hs[h].dt * a1;
             }
+            sv = y + dt * a0;
           }
-          float ko[NH][2] = {};
-          feval(sv, ko);
+          const float ko = feval(sv);
 #pragma unroll
-          for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int j = 0; j < 7; ++j)
-              if (j == s) {
-                hs[h].k[j][0] = ko[h][0];
-                hs[h].k[j][1] = ko[h][1];
-              }
+          for (int j = 0; j < 7; ++j)
+            if (j == s) k[j] = ko;
         }
         // y1 = y + dt * sum b_j k_j   (FSAL: b_last = 0 and the sum equals the last stage's argument)
-        float y1[NH][2], er[NH][2];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          float s0 = 0.f, s1 = 0.f, e0 = 0.f, e1 = 0.f;
+        float s0 = 0.f, e0 = 0.f;
+        {
           bool fb = true, fe = true;
 #pragma unroll
           for (int j = 0; j < 7; ++j) {
             if (j < S) {
               const float bj = a.tab.b[j];
               if (bj != 0.f) {
-                s0 = fb ? hs[h].k[j][0] * bj : s0 + hs[h].k[j][0] * bj;
-                s1 = fb ? hs[h].k[j][1] * bj : s1 + hs[h].k[j][1] * bj;
+                s0 = fb ? k[j] * bj : s0 + k[j] * bj;
                 fb = false;
               }
               const float ej = a.tab.e[j];
               if (a.tab.has_err && ej != 0.f) {
-                e0 = fe ? hs[h].k[j][0] * ej : e0 + hs[h].k[j][0] * ej;
-                e1 = fe ? hs[h].k[j][1] * ej : e1 + hs[h].k[j][1] * ej;
+                e0 = fe ? k[j] * ej : e0 + k[j] * ej;
                 fe = false;
               }
             }
           }
-          y1[h][0] = hs[h].y[0] + hs[h].dt * s0;
-          y1[h][1] = hs[h].y[1] + hs[h].dt * s1;
-          er[h][0] = hs[h].dt * e0;
-          er[h][1] = hs[h].dt * e1;
         }
-        bool accept[NH];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) accept[h] = true;
+        const float y1 = y + dt * s0;
+        const float er = dt * e0;
+        bool accept = true;
         if (a.tab.has_err) {
           // per-row RMS of err / (atol + rtol*max(|y0|,|y1|)) over all F columns (torchode rms_norm)
-          __syncthreads();  // red free
-#pragma unroll
-          for (int h = 0; h < NH; ++h) {
+          __syncthreads();  // qb free
+          if (tid < 256) {
             float q = 0.f;
-#pragma unroll
-            for (int ci = 0; ci < 2; ++ci) {
-              if (colv[ci]) {
-                const float bound = a.atol + a.rtol * fmaxf(fabsf(hs[h].y[ci]), fabsf(y1[h][ci]));
-                const float z = er[h][ci] / bound;
-                q += z * z;
-              }
+            if (owner) {
+              const float bound = a.atol + a.rtol * fmaxf(fabsf(y), fabsf(y1));
+              const float z = er / bound;
+              q = z * z;
             }
-            q += __shfl_xor(q, 16, 64);
-            q += __shfl_xor(q, 32, 64);
-            if ((tid & 63) < 16) hs[h].red[(tid >> 6) * 16 + ks] = q;
+            qb[tid] = q;
           }
           __syncthreads();
           ++c.epoch;
-#pragma unroll
-          for (int h = 0; h < NH; ++h) {
-            if (hs[h].active && tid < R) {
-              const float* red = hs[h].red;
-              const float s = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
-              put(buf_of(hs[h], c.epoch) + tid * INTEG_MEMBERS + cu, s, c.epoch, c.local);
-            }
+          if (tid < R) {
+            float s = 0.f;
+            for (int cl = 0; cl < NCF; ++cl) s += qb[cl * RT + tid];
+            put(buf_of(c, c.epoch) + tid * INTEG_MEMBERS + cu, s, c.epoch, c.local);
           }
-#pragma unroll
-          for (int h = 0; h < NH; ++h) {
-            if (!hs[h].active) continue;
-            gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, R * INTEG_MEMBERS, hs[h].nrm);
-            float tot = 0.f;
-            const int rr = hs[h].has_row ? ks : 0;
-            for (int m = 0; m < INTEG_MEMBERS; ++m) tot += hs[h].nrm[rr * INTEG_MEMBERS + m];
-            const float ratio = sqrtf(tot / (float)F);
-            accept[h] = ratio < 1.0f;
-            float factor = 0.9f * powf(ratio, inv_order);
-            factor = fminf(fmaxf(factor, 0.2f), 10.0f);
-            hs[h].dtn = hs[h].dt * factor;
-          }
+          gather<MAXG>(c, buf_of(c, c.epoch), c.epoch, R, INTEG_MEMBERS, INTEG_MEMBERS, nrm);
+          float tot = 0.f;
+          const int rr = orow < R ? orow : 0;
+          for (int m = 0; m < INTEG_MEMBERS; ++m) tot += nrm[rr * INTEG_MEMBERS + m];
+          const float ratio = sqrtf(tot / (float)F);
+          accept = ratio < 1.0f;
+          float factor = 0.9f * powf(ratio, inv_order);
+          factor = fminf(fmaxf(factor, 0.2f), 10.0f);
+          dtn = dt * factor;
         } else {
-#pragma unroll
-          for (int h = 0; h < NH; ++h) hs[h].dtn = hs[h].dt;
+          dtn = dt;
         }
+        const bool upd = accept && running;
+        if (running) ++n_steps;
+        if (upd) {
+          ++n_acc;
+          y = y1;
+          if (a.tab.fsal) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          Half<RT>& H = hs[h];
-          const bool upd = accept[h] && H.running;
-          if (H.running) ++H.n_steps;
-          if (upd) {
-            ++H.n_acc;
-            H.y[0] = y1[h][0];
-            H.y[1] = y1[h][1];
-            if (a.tab.fsal) {
-#pragma unroll
-              for (int j = 0; j < 7; ++j)
-                if (j == S - 1) {
-                  H.k[0][0] = H.k[j][0];
-                  H.k[0][1] = H.k[j][1];
-                }
-            }
+            for (int j = 0; j < 7; ++j)
+              if (j == S - 1) k[0] = k[j];
           }
-          if (fixed) {
-            if (--H.sub_left <= 0) H.running = false;
-          } else {
-            if (upd) H.t = H.last ? H.t1 : H.t + H.dt;
-            H.running = H.row_valid && (H.t < H.t1);
-            const float span = H.t1 - H.t;
-            H.last = H.dtn >= span;
-            H.dt = H.last ? span : H.dtn;
-          }
+        }
+        if (fixed) {
+          if (--sub_left <= 0) running = false;
+        } else {
+          if (upd) t = last ? t1 : t + dt;
+          running = row_valid && (t < t1);
+          const float span = t1 - t;
+          last = dtn >= span;
+          dt = last ? span : dtn;
         }
         have_k1 = a.tab.fsal != 0;
       }
@@ -792,140 +556,63 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
     if (!seq_mode || c.failed) break;
 
     // ======================= RNN phase =======================
-    // 1. all-gather the evolved states h~ [R][F] of each half -> hst
+    // 1. all-gather the evolved states h~ [R][F] -> hst
     ++c.epoch;
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      if (hs[h].active && hs[h].has_row) {
-        u64* buf = buf_of(hs[h], c.epoch);
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-          if (colv[ci]) put(buf + ks * F + colg[ci], hs[h].y[ci], c.epoch, c.local);
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-      if (hs[h].active) gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, R * F, hs[h].hst);
+    if (owner) put(buf_of(c, c.epoch) + orow * F + ocg, y, c.epoch, c.local);
+    gather<MAXG>(c, buf_of(c, c.epoch), c.epoch, R, F, Fp, hst);
     const int NCV = a.rnn_vcols * NCF;
-    // Both halves share one pass over the streamed RNN weights: rows r = h*RT + bi of a 2*RT-row product read
-    // their inputs from their own half's LDS block (the blocks sit lds_half_stride floats apart).
-    constexpr bool JOINT = NH == 2 && RT <= 4;
-    constexpr int RR = JOINT ? 2 * RT : RT;
     for (int l = 0; l < a.L; ++l) {
       const bool more = l + 1 < a.L;
-      const float* wsl = a.rw[l] + (size_t)cu * NCV * 2 * F;
+      const float* wsl = a.rw[l] + (size_t)cu * NCV * 2 * Fp;
       const float* rb = a.rb[l];
       // ---- inputs of this layer: the fused features (l = 0) or the gathered h' of the layer below
       if (l == 0) {
         __syncthreads();
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          if (!hs[h].active) continue;
-          const int first = a.b_begin + (g * NH + h) * BPH;
-          for (int i = tid; i < BPH * F; i += 256) {
-            const int bi = i / F;
-            const int b = first + bi;
-            hs[h].xin[i] = (b < a.b_end) ? a.fused[((size_t)b * a.P + it) * F + (i - bi * F)] : 0.f;
-          }
+        for (int i = tid; i < BPG * Fp; i += NT) {
+          const int bi = i / Fp, col = i - bi * Fp;
+          const int b = a.b_begin + g * BPG + bi;
+          xin[i] = (b < a.b_end && col < F) ? a.fused[((size_t)b * a.P + it) * F + col] : 0.f;
         }
         __syncthreads();
       } else {
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-          if (hs[h].active) gather<MAXG>(c, buf_of(hs[h], c.epoch), c.epoch, BPH * F, hs[h].xin);
+        gather<MAXG>(c, buf_of(c, c.epoch), c.epoch, BPG, F, Fp, xin);
       }
-      // ---- pre-activations
+      // ---- pre-activations for every virtual column of this member
       const unsigned long long sr0 = STAMP_NOW();
-      if (JOINT) {
-        int offa[RR], offb[RR];
+      int offa[RT], offb[RT];
 #pragma unroll
-        for (int r = 0; r < RR; ++r) {
-          const int hh = (r / RT) < NH && (r / RT == 0 ? hs[0].active : hs[NH - 1].active) ? r / RT : 0;
-          const int bi = (r % RT) < BPH ? (r % RT) : BPH - 1;
-          offa[r] = hh * a.lds_half_stride + bi * F;
-          offb[r] = hh * a.lds_half_stride + (l * BPH + bi) * F;
-        }
-        const int kh = ks / RT, kb = ks - kh * RT;  // the (half, sequence) whose total reduce_rows leaves on this lane
-        const bool mine = kh < NH && kb < BPH && (kh == 0 ? hs[0].active : hs[NH - 1].active);
-        float* pre_k = hs[0].pre + kh * a.lds_half_stride;
-        for (int pass = 0; pass * 32 < NCV; ++pass) {
-          float res[2];
-          layer<RR>(wsl, nullptr, NCV, F, hs[0].xin, offa, F, hs[0].hst, offb, pass * 32 + slot, ks, res);
-          if (mine) {
-#pragma unroll
-            for (int ci = 0; ci < 2; ++ci) {
-              const int cl = pass * 32 + ci * 16 + slot;
-              if (cl < NCV) pre_k[cl * RT + kb] = res[ci];
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          if (!hs[h].active) continue;
-          int offa[RT], offb[RT];
-#pragma unroll
-          for (int r = 0; r < RT; ++r) {
-            const int bi = r < BPH ? r : BPH - 1;
-            offa[r] = bi * F;
-            offb[r] = (l * BPH + bi) * F;
-          }
-          for (int pass = 0; pass * 32 < NCV; ++pass) {
-            float res[2];
-            layer<RT>(wsl, nullptr, NCV, F, hs[h].xin, offa, F, hs[h].hst, offb, pass * 32 + slot, ks, res);
-            if (ks < BPH) {
-#pragma unroll
-              for (int ci = 0; ci < 2; ++ci) {
-                const int cl = pass * 32 + ci * 16 + slot;
-                if (cl < NCV) hs[h].pre[cl * RT + ks] = res[ci];
-              }
-            }
-          }
-        }
+      for (int r = 0; r < RT; ++r) {
+        const int bi = r < BPG ? r : BPG - 1;
+        offa[r] = bi * Fp;
+        offb[r] = (l * BPG + bi) * Fp;
       }
+      for (int pass = 0; pass * 32 < NCV; ++pass)
+        layer<RT>(wsl, NCV, Fp, xin, offa, Fp, hst, offb, pass * 32 + wave, lane, lay);
       STAMP_ADD(c.t_rnn, sr0);
       __syncthreads();
-      // ---- gates / tanh on the owning lanes, new hidden state
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        Half<RT>& H = hs[h];
-        if (!H.active) continue;
-        const int first = a.b_begin + (g * NH + h) * BPH;
-        if (ks < BPH) {
-          const int b = first + ks;
-#pragma unroll
-          for (int ci = 0; ci < 2; ++ci) {
-            const int ul = ci * 16 + slot;
-            if (ul >= NCF) continue;
-            const int ug = cu * NCF + ul;
-            float hv;
-            if (a.rnn_type == 0) {
-              hv = tanhf(H.pre[ul * RT + ks] + rb[ug]);
-            } else {
-              const float rg = sigmoidf_(H.pre[ul * RT + ks] + rb[ug]);
-              const float zg = sigmoidf_(H.pre[(NCF + ul) * RT + ks] + rb[F + ug]);
-              const float ng = tanhf(H.pre[(2 * NCF + ul) * RT + ks] + rb[2 * F + ug] +
-                                     rg * (H.pre[(3 * NCF + ul) * RT + ks] + rb[3 * F + ug]));
-              const float hp = H.hst[((size_t)l * BPH + ks) * F + ug];
-              hv = (1.f - zg) * ng + zg * hp;
-            }
-            H.mv[(l * BPH + ks) * 32 + ul] = hv;
-            if (!more && b < a.b_end) a.out_seq[((size_t)b * a.P + it) * F + ug] = hv;
-            if (more) put(buf_of(H, c.epoch + 1) + ks * F + ug, hv, c.epoch + 1, c.local);
-          }
+      // ---- gates / tanh on the owner threads (row index = sequence within the group), new hidden state
+      if (ocl < NCF && orow < BPG) {
+        const int b = a.b_begin + g * BPG + orow;
+        const int ug = cu * NCF + ocl;
+        float hv;
+        if (a.rnn_type == 0) {
+          hv = tanhf(lay[ocl * RT + orow] + rb[ug]);
+        } else {
+          const float rg = sigmoidf_(lay[ocl * RT + orow] + rb[ug]);
+          const float zg = sigmoidf_(lay[(NCF + ocl) * RT + orow] + rb[F + ug]);
+          const float ng = tanhf(lay[(2 * NCF + ocl) * RT + orow] + rb[2 * F + ug] +
+                                 rg * (lay[(3 * NCF + ocl) * RT + orow] + rb[3 * F + ug]));
+          const float hp = hst[(l * BPG + orow) * Fp + ug];
+          hv = (1.f - zg) * ng + zg * hp;
         }
+        mv[(l * BPG + orow) * 32 + ocl] = hv;
+        if (!more && b < a.b_end) a.out_seq[((size_t)b * a.P + it) * F + ug] = hv;
+        if (more) put(buf_of(c, c.epoch + 1) + orow * F + ug, hv, c.epoch + 1, c.local);
       }
       if (more) ++c.epoch;
     }
     __syncthreads();
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      if (hs[h].has_row) {
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-          if (colv[ci]) hs[h].y[ci] = hs[h].mv[ks * 32 + ci * 16 + slot];
-      }
-    }
+    if (owner) y = mv[orow * 32 + ocl];
     __syncthreads();
   }
 
@@ -941,19 +628,12 @@ __global__ __launch_bounds__(256) void integrator_kernel(const IntegArgs a) {
   (void)t_begin;
 #endif
   // ---- outputs
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    const Half<RT>& H = hs[h];
-    if (!H.row_valid || c.failed) continue;
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-      if (!colv[ci]) continue;
-      if (seq_mode) a.hT[(size_t)H.grow * F + colg[ci]] = H.y[ci];
-      else a.y_out[(size_t)H.grow * F + colg[ci]] = H.y[ci];
-    }
-    if (a.stats && cu == 0 && slot == 0) {
-      a.stats[2 * H.grow] = H.n_steps;
-      a.stats[2 * H.grow + 1] = H.n_acc;
+  if (owner && row_valid && !c.failed) {
+    if (seq_mode) a.hT[(size_t)grow * F + ocg] = y;
+    else a.y_out[(size_t)grow * F + ocg] = y;
+    if (a.stats && cu == 0 && ocl == 0) {
+      a.stats[2 * grow] = n_steps;
+      a.stats[2 * grow + 1] = n_acc;
     }
   }
 }
@@ -967,7 +647,7 @@ static int launch_rt(const IntegArgs& a, size_t lds_bytes, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(integrator_kernel<RT>, dim3(INTEG_GROUPS * INTEG_MEMBERS), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL(integrator_kernel<RT>, dim3(INTEG_GROUPS * INTEG_MEMBERS), dim3(INTEG_THREADS), lds_bytes, st, a);
   return 0;
 }
 
