@@ -60,7 +60,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 struct Ctx {
-  unsigned long long t_gather, t_layer, t_rnn, n_gather;
+  unsigned long long t_gather, t_layer, t_rnn, n_gather, t_bar, t_epi;
   int tid, lane, wave, cu;
   unsigned epoch;
   bool local;   // all members of this group share one XCD (verified, not assumed)
@@ -91,11 +91,12 @@ __device__ __forceinline__ unsigned xcc_id() {
 
 // Collect the n = rows*width granules of exchange `tag` into LDS: value (row, col) goes to dst[row*ld + col];
 // columns width..ld-1 of every row are zero-filled (K is padded to the 256-wide chunks of the layer product).
-// Workgroup-uniform outcome.
+// PRECONDITION: a workgroup barrier has passed since the last read of dst (every caller has one right after the
+// layer product that consumed it), so waves may start polling while the owner threads of THIS member are still
+// publishing - their epilogue hides under the wait for the other members.  Ends with a barrier; uniform outcome.
 template <int MAXG>
 __device__ __forceinline__ void gather(Ctx& c, const u64* buf, unsigned tag, int rows, int width, int ld, float* dst) {
   const unsigned long long st0 = STAMP_NOW();
-  __syncthreads();  // every wave is done reading dst's previous contents
   bool fail = false;
   const int n = rows * width;
   if (ld > width) {
@@ -267,16 +268,38 @@ __device__ __forceinline__ void layer(const float* __restrict__ wbase, int NC, i
   }
 }
 
+// tanh on the owner threads sits on the critical path of every exchange (one or two waves run it while the
+// rest of the workgroup waits), and ocml's tanhf is ~150 dependent instructions.  This form is ~20:
+// |x| < 0.25: odd Taylor polynomial to x^11 (truncation < 2e-9 relative); otherwise 1 - 2/(e^{2|x|} + 1) with the
+// exponent's rounding error carried in a compensation term.  Absolute error < 2e-7 everywhere (fp32 eps 1.2e-7),
+// far inside the 1e-4 parity bar; tests compare against torch's tanh.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  float p = fmaf(x2, -0.00886323552990220f, 0.0218694885361552f);  // -1382/155925, 62/2835
+  p = fmaf(x2, p, -0.0539682539682540f);                            // -17/315
+  p = fmaf(x2, p, 0.133333333333333f);                              // 2/15
+  p = fmaf(x2, p, -0.333333333333333f);                             // -1/3
+  const float small = fmaf(x * x2, p, x);
+  // e^{2|x|} = 2^(a + b): a = fl(2|x| * log2e), b = the rounding error of that product plus the low part of log2e
+  const float a = ax * 2.885390043f;                                 // 2*log2(e) (hi)
+  const float b = fmaf(ax, 2.885390043f, -a) + ax * 3.851925e-8f;    // 2*log2(e) (lo) = 2*1.9259629e-8
+  const float e = __builtin_amdgcn_exp2f(a) * fmaf(b, 0.693147181f, 1.0f);
+  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float r = ax < 0.25f ? small : copysignf(big, x);
+  return ax > 20.0f ? copysignf(1.0f, x) : r;
+}
+
 __device__ __forceinline__ float hidden_act(float v, int act) {
   switch (act) {
-    case 0: return tanhf(v);
+    case 0: return fast_tanh(v);
     case 1: return fmaxf(v, 0.f);
     case 2: return v > 0.f ? v : 0.01f * v;
     default: return v > 20.f ? v : log1pf(expf(v));  // nn.Softplus(beta=1, threshold=20)
   }
 }
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float sigmoidf_(float v) { return 0.5f * fast_tanh(0.5f * v) + 0.5f; }
 
 __device__ __forceinline__ int pad256(int k) { return (k + 255) & ~255; }
 
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
   c.local = false;
   c.xb = a.xbuf + (size_t)(2 * g) * a.xstride;
   c.xstride = a.xstride;
-  c.t_gather = c.t_layer = c.t_rnn = c.n_gather = 0;
+  c.t_gather = c.t_layer = c.t_rnn = c.n_gather = c.t_bar = c.t_epi = 0;
   const unsigned long long t_begin = STAMP_NOW();
   const int tid = c.tid, lane = c.lane, wave = c.wave, cu = c.cu;
 
@@ -390,13 +413,17 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
       else
         layer<RT>(a.w[l] + (size_t)cu * NC * Kp, NC, Kp, xin, off_ode, 0, xin, off_ode, wave, lane, lay);
       STAMP_ADD(c.t_layer, sl0);
+      const unsigned long long sb0 = STAMP_NOW();
       __syncthreads();
+      STAMP_ADD(c.t_bar, sb0);
+      const unsigned long long se0 = STAMP_NOW();
       // owners of this layer's outputs: thread t < NC*RT -> (row t % RT, column t / RT)
       if (ocl < NC && orow < R) {
         const float v = lay[tid] + bia[l * 32 + ocl];
         if (more) put(buf_of(c, c.epoch + 1) + orow * N + cu * NC + ocl, hidden_act(v, a.act), c.epoch + 1, c.local);
-        else ko = tanhf(v);
+        else ko = fast_tanh(v);
       }
+      STAMP_ADD(c.t_epi, se0);
       if (more) ++c.epoch;
     }
     return ko;
@@ -596,11 +623,11 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
         const int ug = cu * NCF + ocl;
         float hv;
         if (a.rnn_type == 0) {
-          hv = tanhf(lay[ocl * RT + orow] + rb[ug]);
+          hv = fast_tanh(lay[ocl * RT + orow] + rb[ug]);
         } else {
           const float rg = sigmoidf_(lay[ocl * RT + orow] + rb[ug]);
           const float zg = sigmoidf_(lay[(NCF + ocl) * RT + orow] + rb[F + ug]);
-          const float ng = tanhf(lay[(2 * NCF + ocl) * RT + orow] + rb[2 * F + ug] +
+          const float ng = fast_tanh(lay[(2 * NCF + ocl) * RT + orow] + rb[2 * F + ug] +
                                  rg * (lay[(3 * NCF + ocl) * RT + orow] + rb[3 * F + ug]));
           const float hp = hst[(l * BPG + orow) * Fp + ug];
           hv = (1.f - zg) * ng + zg * hp;
@@ -623,6 +650,8 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
     a.dbg[2] = c.t_layer;
     a.dbg[3] = c.t_rnn;
     a.dbg[4] = c.n_gather;
+    a.dbg[6] = c.t_bar;
+    a.dbg[7] = c.t_epi;
   }
 #else
   (void)t_begin;
