@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // ---- loader role: rows lrow + 32q, one float4 at column lc4*4
   const int lrow = tid >> 3;
   const int lc4 = (tid & 7) * 4;
-  const float* a_img[4];
+  const float* a_row[4];  // pixel (hi0, wi0) of the row's receptive field + this thread's 4 channels (may lie outside the image)
   int a_hi0[4], a_wi0[4];
   const float* b_row[4];
   const int HoWo = a.Ho * a.Wo;
@@ -48,16 +48,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int rem = m - img * HoWo;
       const int ho = rem / a.Wo;
       const int wo = rem - ho * a.Wo;
-      a_img[q] = a.in + (size_t)img * a.Hi * a.Wi * a.Cin;
       a_hi0[q] = ho * a.stride - a.pad;
       a_wi0[q] = wo * a.stride - a.pad;
+      a_row[q] = a.in + ((size_t)img * a.Hi * a.Wi + (ptrdiff_t)a_hi0[q] * a.Wi + a_wi0[q]) * a.Cin + lc4;
     } else {
-      a_img[q] = a.in;
+      a_row[q] = a.in;
       a_hi0[q] = -(1 << 28);
       a_wi0[q] = -(1 << 28);
     }
     const int n = n0 + lrow + 32 * q;
-    b_row[q] = (n < a.Cout) ? a.w + (size_t)n * taps * a.Cin : nullptr;
+    b_row[q] = (n < a.Cout) ? a.w + (size_t)n * taps * a.Cin + lc4 : nullptr;
   }
 
   const int cpt = a.Cin / BK;  // cin chunks per tap
@@ -69,29 +69,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 
   f32x4 ra[4], rb[4];
-  auto load_tile = [&](int kt) {
+  // K-tile coordinates (workgroup-uniform scalars): tap (kh, kw), offset of the tap+chunk inside a pixel row / a filter
+  int t_kh = 0, t_kw = 0, t_cc = 0, t_aoff = 0, t_boff = 0;
+  auto set_tile = [&](int kt) {  // once, for the first tile of this workgroup
     const int tap = kt / cpt;
-    const int cc = (kt - tap * cpt) * BK + lc4;
-    const int kh = tap / a.KW;
-    const int kw = tap - kh * a.KW;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int hi = a_hi0[q] + kh, wi = a_wi0[q] + kw;
-      const bool ok = (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(a_img[q] + ((size_t)hi * a.Wi + wi) * a.Cin + cc);
-      ra[q] = v;
-      f32x4 u = {0.f, 0.f, 0.f, 0.f};
-      if (b_row[q]) u = *reinterpret_cast<const f32x4*>(b_row[q] + (size_t)tap * a.Cin + cc);
-      rb[q] = u;
+    t_cc = (kt - tap * cpt) * BK;
+    t_kh = tap / a.KW;
+    t_kw = tap - t_kh * a.KW;
+    t_aoff = (t_kh * a.Wi + t_kw) * a.Cin + t_cc;
+    t_boff = tap * a.Cin + t_cc;
+  };
+  auto next_tile = [&]() {  // advance (kh, kw, cin-chunk) by one K-tile without divisions
+    t_cc += BK;
+    t_aoff += BK;
+    t_boff += BK;  // filter taps are contiguous: tap*Cin + cc simply keeps counting
+    if (t_cc == a.Cin) {
+      t_cc = 0;
+      ++t_kw;
+      t_aoff -= a.Cin;
+      t_aoff += a.Cin;  // next pixel to the right starts exactly Cin floats later
+      if (t_kw == a.KW) {
+        t_kw = 0;
+        ++t_kh;
+        t_aoff += (a.Wi - a.KW) * a.Cin;  // first tap of the next filter row
+      }
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * q) * LDS_LD + lc4]) = ra[q];
-      *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * q) * LDS_LD + lc4]) = rb[q];
-    }
+  // Loads are UNCONDITIONAL (out-of-image taps / out-of-range rows read a clamped, valid address) and the zero
+  // fill is a select at LDS-store time.  A predicated load (`if (ok) v = *p; else v = 0`) makes hipcc zero the
+  // destination first and guard that write with s_waitcnt vmcnt(0): every load then waits for all earlier ones,
+  // the eight loads of a tile serialise on memory latency and the in-order wave cannot issue MFMAs meanwhile.
+  bool oka[4];
+  auto load_a = [&](int q) {
+    oka[q] = (unsigned)(a_hi0[q] + t_kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + t_kw) < (unsigned)a.Wi;
+    const float* p = oka[q] ? a_row[q] + t_aoff : a.in + lc4;
+    ra[q] = *reinterpret_cast<const f32x4*>(p);
+  };
+  auto load_b = [&](int q) {
+    const float* p = b_row[q] ? b_row[q] + t_boff : a.w + lc4;
+    rb[q] = *reinterpret_cast<const f32x4*>(p);
+  };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto store_a = [&](int buf, int q) {
+    *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * q) * LDS_LD + lc4]) = oka[q] ? ra[q] : zero4;
+  };
+  auto store_b = [&](int buf, int q) {
+    *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * q) * LDS_LD + lc4]) = b_row[q] ? rb[q] : zero4;
   };
 
   f32x16 acc[2][2];
@@ -107,31 +130,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int b_off = (wn * 64 + fi) * LDS_LD + fh * 16;
 
   if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
+    set_tile(kt_begin);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      load_a(q);
+      load_b(q);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      store_a(0, q);
+      store_b(0, q);
+    }
   }
   __syncthreads();
+  // Main loop.  A wave issues in order, and an MFMA occupies the matrix pipe for 64 cycles but the issue port for
+  // only a few: everything else this wave has to do for the NEXT tile (8 global loads with their address
+  // arithmetic, later the 8 LDS stores, the fragment reads of the next k-group) is placed BETWEEN the MFMAs of the
+  // current tile, one piece per slot of four MFMAs, and sched_barrier(0) keeps the compiler from clustering it
+  // back in front of the MFMA stream.  Only the first fragment read after the barrier is exposed.
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
-    const bool more = (kt + 1 < kt_end);
-    if (more) load_tile(kt + 1);
+    // Branch-free body: the last iteration simply re-stages one more (unused) tile.  With an `if (more)` around each
+    // piece every piece becomes its own basic block and hipcc opens each with s_waitcnt vmcnt(0).
+    if (kt + 1 < kt_end) next_tile();
     const float* Ab = &As[buf][a_off];
     const float* Bb = &Bs[buf][b_off];
+    f32x4 fa[2][2], fb[2][2];
+    fa[0][0] = *reinterpret_cast<const f32x4*>(Ab);
+    fa[0][1] = *reinterpret_cast<const f32x4*>(Ab + 32 * LDS_LD);
+    fb[0][0] = *reinterpret_cast<const f32x4*>(Bb);
+    fb[0][1] = *reinterpret_cast<const f32x4*>(Bb + 32 * LDS_LD);
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + k4 * 4);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + 32 * LDS_LD + k4 * 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bb + k4 * 4);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bb + 32 * LDS_LD + k4 * 4);
+    for (int g = 0; g < 4; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g < 3) {
+        fa[nxt][0] = *reinterpret_cast<const f32x4*>(Ab + (g + 1) * 4);
+        fa[nxt][1] = *reinterpret_cast<const f32x4*>(Ab + 32 * LDS_LD + (g + 1) * 4);
+        fb[nxt][0] = *reinterpret_cast<const f32x4*>(Bb + (g + 1) * 4);
+        fb[nxt][1] = *reinterpret_cast<const f32x4*>(Bb + 32 * LDS_LD + (g + 1) * 4);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+        const int slot = g * 4 + e;
+        if (slot < 4) load_a(slot);
+        else if (slot < 8) load_b(slot - 4);
+        else if (slot < 12) store_a(buf ^ 1, slot - 8);
+        else store_b(buf ^ 1, slot - 12);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][e], fb[cur][0][e], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][e], fb[cur][1][e], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][e], fb[cur][0][e], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][e], fb[cur][1][e], acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
 
