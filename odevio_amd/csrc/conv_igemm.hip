@@ -176,39 +176,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         else if (slot < 8) load_b(slot - 4);
         else if (slot < 12) store_a(buf ^ 1, slot - 8);
         else store_b(buf ^ 1, slot - 12);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][e], fb[cur][0][e], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][e], fb[cur][1][e], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][e], fb[cur][0][e], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][e], fb[cur][1][e], acc[1][1], 0, 0, 0);
+        // D = W-fragment (MFMA rows = output channels) x pixel-fragment (MFMA columns = pixels): a lane then holds
+        // 4 CONSECUTIVE channels of one pixel in registers 4g..4g+3, i.e. one 16-byte NHWC store per group.
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][0][e], fa[cur][0][e], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][1][e], fa[cur][0][e], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][0][e], fa[cur][1][e], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][1][e], fa[cur][1][e], acc[1][1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  C/D map of the 32x32 MFMA: column (= pixel) = lane&31, row (= channel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool vec_ok = (a.Cout % 4 == 0) && (a.ld_out % 4 == 0) && (a.mul == nullptr || a.ld_mul % 4 == 0);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
+    const int m = m0 + wm * 64 + mt * 32 + fi;
+    if (m >= a.M) continue;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const int n = n0 + wn * 64 + nt * 32 + fi;
-      if (n >= a.Cout) continue;
-      float sc = 1.f, sh = 0.f;
-      if (a.splitk <= 1) {
-        if (a.scale) sc = a.scale[n];
-        if (a.shift) sh = a.shift[n];
-      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m >= a.M) continue;
-        float v = acc[mt][nt][r];
-        if (a.splitk > 1) {
-          a.partial[((size_t)blockIdx.z * a.M + m) * a.Cout + n] = v;
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * fh;  // first of 4 consecutive channels
+        if (n >= a.Cout) continue;
+        f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+        if (vec_ok) {  // n % 4 == 0 and Cout % 4 == 0  =>  n + 3 < Cout
+          if (a.splitk > 1) {
+            *reinterpret_cast<f32x4*>(a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
+          } else {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+            if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_epi(v[e] * sc[e] + sh[e], a.act, a.slope);
+            if (a.mul) {
+              const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mul + (size_t)m * a.ld_mul + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= mu[e];
+            }
+            *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ld_out + n) = v;
+          }
         } else {
-          v = apply_epi(v * sc + sh, a.act, a.slope);
-          if (a.mul) v *= a.mul[(size_t)m * a.ld_mul + n];
-          a.out[(size_t)m * a.ld_out + n] = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e >= a.Cout) continue;
+            if (a.splitk > 1) {
+              a.partial[((size_t)blockIdx.z * a.M + m) * a.Cout + n + e] = v[e];
+            } else {
+              float x = apply_epi(v[e] * (a.scale ? a.scale[n + e] : 1.f) + (a.shift ? a.shift[n + e] : 0.f), a.act, a.slope);
+              if (a.mul) x *= a.mul[(size_t)m * a.ld_mul + n + e];
+              a.out[(size_t)m * a.ld_out + n + e] = x;
+            }
+          }
         }
       }
     }
@@ -286,18 +306,22 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
     const int b = pair / (a.S - 1), fr = pair - b * (a.S - 1);
     const float* base = a.img + ((size_t)b * a.S + fr) * 3 * plane;
     const int gy0 = 2 * ty * C1_TH - 3, gx0 = 2 * tx * C1_TW - 3;
+    // element idx = tid + 256 j of the [6][21][69] patch, walked without divisions: +256 = +3 rows +49 columns
+    int x = tid % C1_PW, yy = tid / C1_PW;  // yy = c*21 + y (< 126)
 #pragma unroll
     for (int j = 0; j < C1_PATCH_PER_THREAD; ++j) {
-      const int idx = tid + 256 * j;
-      float v = 0.f;
-      if (idx < C1_PATCH) {
-        const int c = idx / (C1_PH * C1_PW);
-        const int r = idx - c * (C1_PH * C1_PW);
-        const int y = r / C1_PW, x = r - y * C1_PW;
-        const int gy = gy0 + y, gx = gx0 + x;
-        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v = base[c * plane + (size_t)gy * a.W + gx];
+      const int c = yy / C1_PH, y = yy - c * C1_PH;  // constant divisor: one mul-hi
+      const int gy = gy0 + y, gx = gx0 + x;
+      const bool ok = yy < 6 * C1_PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const float* p = ok ? base + c * plane + (size_t)gy * a.W + gx : base;
+      const float v = *p;  // unconditional load from a clamped address (see conv_igemm_kernel)
+      stage[j] = ok ? v : 0.f;
+      x += 256 % C1_PW;
+      yy += 256 / C1_PW;
+      if (x >= C1_PW) {
+        x -= C1_PW;
+        ++yy;
       }
-      stage[j] = v;
     }
   };
   auto store_patch = [&](float* Ps) {
@@ -332,39 +356,62 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const float* Ap = Ps + a_base;
     const float* Bp = Ws + b_base;
+    // One wave per SIMD here (the workgroup owns the CU's LDS), so nothing hides an LDS round trip except this
+    // wave's own MFMAs: the four operand reads of k-step s+2 are issued before the MFMAs of step s and a
+    // sched_barrier per step keeps hipcc from sinking them back next to their use (it then waits lgkmcnt(0)
+    // in front of every group of four MFMAs and the matrix pipe idles ~40 % of the time).
+    constexpr int C1_PF = 2;  // prefetch distance in k-steps
+    float fa0[C1_PF + 1], fa1[C1_PF + 1], fb0[C1_PF + 1], fb1[C1_PF + 1];
+    auto frag_off = [](int s) { return ((s / 49) * C1_PH + (s % 49) / 7) * C1_PW + s % 7; };
+#pragma unroll
+    for (int s = 0; s < C1_PF; ++s) {
+      fa0[s] = Ap[frag_off(s)];
+      fa1[s] = Ap[frag_off(s) + 2 * C1_PW];
+      fb0[s] = Bp[s * 64];
+      fb1[s] = Bp[s * 64 + 32];
+    }
 #pragma unroll
     for (int s = 0; s < C1_KHALF; ++s) {
-      const int c3 = s / 49, kh = (s % 49) / 7, kw = s % 7;
-      const int off = (c3 * C1_PH + kh) * C1_PW + kw;
-      const float a0 = Ap[off];
-      const float a1 = Ap[off + 2 * C1_PW];
-      const float b0 = Bp[s * 64];
-      const float b1 = Bp[s * 64 + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const int cur = s % (C1_PF + 1), nxt = (s + C1_PF) % (C1_PF + 1);
+      if (s + C1_PF < C1_KHALF) {
+        const int off = frag_off(s + C1_PF);
+        fa0[nxt] = Ap[off];
+        fa1[nxt] = Ap[off + 2 * C1_PW];
+        fb0[nxt] = Bp[(s + C1_PF) * 64];
+        fb1[nxt] = Bp[(s + C1_PF) * 64 + 32];
+      }
+      // weights as the MFMA's A operand: channels land on the register axis (16-byte NHWC stores below)
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb0[cur], fa0[cur], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb1[cur], fa0[cur], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb0[cur], fa1[cur], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb1[cur], fa1[cur], acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // epilogue: rows of the MFMA tile are the 32 pixels of one output row segment
+    // epilogue: MFMA columns (lanes) are the 32 pixels of one output row segment, rows (registers) the channels
     {
       const int pair = tile / tiles_per_pair;
       const int t = tile - pair * tiles_per_pair;
       const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+      const int ox = tx * C1_TW + fi;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int oy = ty * C1_TH + 2 * wave + mt;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        float* orow = a.out + (((size_t)pair * a.Ho + oy) * a.Wo + ox) * 64;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const int n = nt * 32 + fi;
-          const float sc = a.scale[n], sh = a.shift[n];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ox = tx * C1_TW + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (oy < a.Ho && ox < a.Wo) {
-              float v = acc[mt][nt][r] * sc + sh;
-              v = v > 0.f ? v : v * a.slope;
-              a.out[(((size_t)pair * a.Ho + oy) * a.Wo + ox) * 64 + n] = v;
+          for (int g = 0; g < 4; ++g) {
+            const int n = nt * 32 + 8 * g + 4 * fh;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
+              v[e] = x > 0.f ? x : x * a.slope;
             }
+            *reinterpret_cast<f32x4*>(orow + n) = v;
           }
         }
       }
