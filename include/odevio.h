@@ -71,6 +71,8 @@ typedef struct odevio_config {
   int32_t rnn_num_layers;
   float atol, rtol, dt0;      /* 1e-6, 1e-2, 1e-4 in the reference */
   int32_t max_steps;          /* per-interval step budget of the adaptive solvers */
+  /* Neural-CDE variant, reference scripts/config.py:74-78 (used when model_type == ODEVIO_MODEL_CDE) */
+  int32_t cde_hidden_dim, cde_fn_num_layers, cde_activation, cde_solver;
 } odevio_config;
 
 /* One named weight, keyed exactly like the reference state_dict, fp32 on device. */
@@ -121,6 +123,12 @@ int odevio_ode_steps(odevio_plan* plan, const float* y, const float* t0, const f
  * fused [B,P,F], ts [B,P+1], hc_in NULL or [L,B,F] -> poses [B,P,6], h_T [L,B,F]. */
 int odevio_ode_rnn_fwd(odevio_plan* plan, const float* fused, const float* ts, const float* hc_in, int32_t B,
                        int32_t P, float* poses, float* h_T, int32_t* stats, void* stream);
+/* PoseCDE.forward after fusion (reference src/models/PoseCDE.py:94-103): obs [B,L,1+F] = [time | fused features] of every
+ * observation so far (device), t_out = the output times ts[0,1:] (HOST doubles, n_out of them), z0_in NULL or a carried
+ * [B,H] state -> poses [B,n_out,6], z0_out [B,H] (the reference returns the INITIAL state).  Host-driven solver
+ * (torchdiffeq-style): synchronises `stream`.  stats_host = {steps, accepted} or NULL. */
+int odevio_cde_fwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, const double* t_out_host, int32_t n_out,
+                   const float* z0_in, float* poses, float* z0_out, int32_t* stats_host, void* stream);
 /* DeepVIO.forward (DeepVIO.py:61-68): img [B,S,3,H,W], imu [B,T,6], ts [B,S], hc NULL or [L,B,F]
  * -> poses [B,S-1,6], h_T [L,B,F]. */
 int odevio_forward(odevio_plan* plan, const float* img, const float* imu, int32_t T, const float* ts,

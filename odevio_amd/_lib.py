@@ -19,7 +19,7 @@ MODEL_TYPES = {"ode-rnn": 0, "rnn": 1, "cde": 2}
 SYMBOLS = [
     "odevio_version", "odevio_last_error", "odevio_plan_create", "odevio_plan_destroy", "odevio_reserve",
     "odevio_check", "odevio_conv_block_fwd", "odevio_image_encoder_fwd", "odevio_imu_encoder_fwd", "odevio_fuse_fwd", "odevio_ode_func",
-    "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
+    "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
 ]
 
 
@@ -34,6 +34,8 @@ class OdevioConfig(ctypes.Structure):
         ("rnn_type", ctypes.c_int32), ("rnn_num_layers", ctypes.c_int32),
         ("atol", ctypes.c_float), ("rtol", ctypes.c_float), ("dt0", ctypes.c_float),
         ("max_steps", ctypes.c_int32),
+        ("cde_hidden_dim", ctypes.c_int32), ("cde_fn_num_layers", ctypes.c_int32),
+        ("cde_activation", ctypes.c_int32), ("cde_solver", ctypes.c_int32),
     ]
 
 
@@ -80,6 +82,7 @@ def load():
     lib.odevio_ode_func.argtypes = [vp, fp, i32, fp, vp]
     lib.odevio_ode_steps.argtypes = [vp, fp, fp, fp, i32, i32, i32, fp, vp, vp]
     lib.odevio_ode_rnn_fwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, vp, vp]
+    lib.odevio_cde_fwd.argtypes = [vp, fp, i32, i32, vp, i32, fp, fp, fp, vp, vp]
     lib.odevio_forward.argtypes = [vp, fp, fp, i32, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_profile_enable.argtypes = [vp, i32]
     lib.odevio_profile_read.argtypes = [vp, fp]

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/odevio.h"
+#include "cde.h"
 #include "common.h"
 #include "integrator.h"
 
@@ -71,6 +72,10 @@ struct odevio_plan {
   unsigned long long* xbuf = nullptr;
   int xstride = 0;
   int* status = nullptr;
+  // Neural-CDE path (model_type cde)
+  CdeModel cde = {};
+  float *cde_init_w = nullptr, *cde_init_b = nullptr;
+  DevBuf cde_ws;
   // workspace (grown on demand)
   DevBuf actA, actB, imu_act, fcat, fused, out_seq, reg_hid, partial, hT_scratch;
   std::vector<void*> owned;
@@ -171,15 +176,31 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (!p) return;
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->hT_scratch})
+                    &p->hT_scratch, &p->cde_ws})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
 
 static int validate(const odevio_config& c) {
   if (c.struct_size != (int)sizeof(odevio_config)) return fail(ODEVIO_ERR_BAD_ARG, "odevio_config size mismatch");
-  if (c.model_type != ODEVIO_MODEL_ODE_RNN && c.model_type != ODEVIO_MODEL_RNN)
-    return fail(ODEVIO_ERR_UNSUPPORTED, "model_type %d is not built yet (ode-rnn and rnn are)", c.model_type);
+  if (c.model_type != ODEVIO_MODEL_ODE_RNN && c.model_type != ODEVIO_MODEL_RNN && c.model_type != ODEVIO_MODEL_CDE)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "model_type %d not supported", c.model_type);
+  if (c.model_type == ODEVIO_MODEL_CDE) {
+    // PoseCDE is only dimensionally consistent when cde_hidden_dim == v_f_len + i_f_len (its reduction_net is never
+    // applied, reference PoseCDE.py:53-61,83-84,96)
+    if (c.cde_hidden_dim != c.v_f_len + c.i_f_len)
+      return fail(ODEVIO_ERR_UNSUPPORTED, "cde_hidden_dim (%d) must equal v_f_len + i_f_len (%d)", c.cde_hidden_dim, c.v_f_len + c.i_f_len);
+    if (c.cde_hidden_dim % 32 || c.cde_fn_num_layers < 1 || c.cde_fn_num_layers + 1 > CDE_MAX_LIN)
+      return fail(ODEVIO_ERR_UNSUPPORTED, "cde_hidden_dim must be a multiple of 32 and cde_fn_num_layers in 1..%d", CDE_MAX_LIN - 1);
+    if (c.cde_activation < 0 || c.cde_activation > 3) return fail(ODEVIO_ERR_BAD_ARG, "Activation function not supported");
+    if (c.cde_solver != ODEVIO_DOPRI5 && c.cde_solver != ODEVIO_RK4 && c.cde_solver != ODEVIO_EULER)
+      return fail(ODEVIO_ERR_BAD_ARG, "Solver not supported");
+    if (c.fuse_method != ODEVIO_FUSE_CAT && c.fuse_method != ODEVIO_FUSE_SOFT)
+      return fail(ODEVIO_ERR_UNSUPPORTED, "fuse method %d has no deterministic device path", c.fuse_method);
+    if (c.img_h < 64 || c.img_w < 64) return fail(ODEVIO_ERR_BAD_ARG, "image size %dx%d too small", c.img_h, c.img_w);
+    if (c.v_f_len % 4 || c.i_f_len % 4) return fail(ODEVIO_ERR_UNSUPPORTED, "feature lengths must be multiples of 4");
+    return 0;
+  }
   if (c.img_h < 64 || c.img_w < 64) return fail(ODEVIO_ERR_BAD_ARG, "image size %dx%d too small", c.img_h, c.img_w);
   if (c.fuse_method != ODEVIO_FUSE_CAT && c.fuse_method != ODEVIO_FUSE_SOFT)
     return fail(ODEVIO_ERR_UNSUPPORTED, "fuse method %d has no deterministic device path", c.fuse_method);
@@ -323,8 +344,31 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       TRY(upload(p, &p->ode_b[l], bias, st));
     }
   }
+  // ---- Neural-CDE: initial layer, CDEFunc (reference PoseCDE.py:59-66, ODEFunc.py:52-58); reduction_net is unused
+  if (cfg->model_type == ODEVIO_MODEL_CDE) {
+    const int Hc = cfg->cde_hidden_dim, C = Hc + 1, nh = cfg->cde_fn_num_layers;
+    TRY(wt.get("Pose_net.initial.0.weight", (int64_t)Hc * C, w));
+    TRY(upload(p, &p->cde_init_w, w, st));
+    TRY(wt.get("Pose_net.initial.0.bias", Hc, bias));
+    TRY(upload(p, &p->cde_init_b, bias, st));
+    p->cde.H = Hc; p->cde.C = C; p->cde.n_hidden = nh; p->cde.act = cfg->cde_activation;
+    p->cde.atol = 1e-6f; p->cde.rtol = 1e-4f;  // PoseCDE.py:101
+    p->cde.solver = cfg->cde_solver == ODEVIO_DOPRI5 ? 0 : (cfg->cde_solver == ODEVIO_EULER ? 2 : 1);
+    p->cde.max_steps = cfg->max_steps;
+    for (int l = 0; l <= nh; ++l) {
+      const std::string pre = "Pose_net.cde_func.net." + std::to_string(2 * l);
+      const int64_t N = l < nh ? Hc : (int64_t)Hc * C;
+      float *dw = nullptr, *db = nullptr;
+      TRY(wt.get(pre + ".weight", N * Hc, w));
+      TRY(upload(p, &dw, w, st));
+      TRY(wt.get(pre + ".bias", N, bias));
+      TRY(upload(p, &db, bias, st));
+      p->cde.w[l] = dw;
+      p->cde.b[l] = db;
+    }
+  }
   // ---- RNN stack: virtual columns over K = [input | hidden]
-  {
+  if (cfg->model_type != ODEVIO_MODEL_CDE) {
     const int L = cfg->rnn_num_layers;
     const bool gru = cfg->rnn_type == ODEVIO_RNN_GRU;
     const int gates = gru ? 3 : 1;
@@ -780,6 +824,38 @@ extern "C" int odevio_ode_rnn_fwd(odevio_plan* p, const float* fused, const floa
   rc = regress(p, p->out_seq.p, B * P, poses, st);
   stage_mark(p, 6, st);
   return rc;
+}
+
+extern "C" int odevio_cde_fwd(odevio_plan* p, const float* obs, int32_t B, int32_t L, const double* t_out_host,
+                              int32_t n_out, const float* z0_in, float* poses, float* z0_out, int32_t* stats_host,
+                              void* stream) {
+  ARGCHK(p && obs && t_out_host && poses && z0_out && B > 0 && L > 1 && n_out > 0, "odevio_cde_fwd: bad argument");
+  if (p->cfg.model_type != ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "plan is not a Neural-CDE plan");
+  hipStream_t st = (hipStream_t)stream;
+  const int H = p->cde.H, C = p->cde.C, n = B * H;
+  int rc;
+  const size_t need = (size_t)B * C + 24 * (size_t)n + 16 + (size_t)B * n_out * H;
+  if ((rc = ensure(p->cde_ws, need))) return rc;
+  float* q = p->cde_ws.p;
+  CdeWork w;
+  w.scal = q; q += 16;
+  w.g = q; q += (size_t)B * C;
+  w.ha = q; q += n; w.hb = q; q += n; w.ytmp = q; q += n; w.y = q; q += n; w.y1 = q; q += n;
+  w.ymid = q; q += n; w.err = q; q += n; w.fnext = q; q += n;
+  w.k = q; q += 7 * (size_t)n;
+  w.interp = q; q += 5 * (size_t)n;
+  float* z0 = q; q += n;
+  float* sol = q;  // [B][n_out][H]
+  // z0 = tanh(initial(X(0))) with X(0) = the first observation (PoseCDE.py:96), unless the caller carries one in
+  if (z0_in) HIPCHK(hipMemcpyAsync(z0, z0_in, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  else cde_launch_linear(obs, L * C, p->cde_init_w, p->cde_init_b, z0, B, C, H, 0 /*tanh*/, st);
+  HIPCHK(hipMemcpyAsync(z0_out, z0, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  int stats[2] = {0, 0};
+  rc = cde_solve(p->cde, w, obs, B, L, t_out_host, n_out, z0, sol, stats, st);
+  if (rc == ODEVIO_ERR_MAX_STEPS) return fail(rc, "cdeint: step budget exhausted");
+  if (rc) return fail(rc, "cdeint failed: %s", hipGetErrorString(hipGetLastError()));
+  if (stats_host) { stats_host[0] = stats[0]; stats_host[1] = stats[1]; }
+  return regress(p, sol, B * n_out, poses, st);
 }
 
 extern "C" int odevio_forward(odevio_plan* p, const float* img, const float* imu, int32_t T, const float* ts,

@@ -94,14 +94,48 @@ class _PoseNet(nn.Module):
         return [p for n, p in self.named_parameters() if not n.startswith("regressor")]
 
 
+class _PoseCDENet(nn.Module):
+    """Parameter container + window history for PoseCDE (reference PoseCDE.py:41-73)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.f_len = opt.v_f_len + opt.i_f_len
+        hc = opt.cde_hidden_dim
+        if opt.cde_activation_fn not in _lib.ACTIVATIONS:
+            raise ValueError(f"Activation function {opt.cde_activation_fn} not supported")
+        if opt.cde_solver not in ("dopri5", "rk4", "runge_kutta", "euler"):
+            raise ValueError(f"Solver {opt.cde_solver} not supported")
+        self.fuse = _Fuse(self.f_len, opt.fuse_method)
+        # constructed but never applied by the reference (PoseCDE.py:53-58); kept for state_dict compatibility
+        self.reduction_net = nn.Sequential(nn.Linear(self.f_len, self.f_len // 2), nn.LeakyReLU(0.1), nn.Linear(self.f_len // 2, hc))
+        self.initial = nn.Sequential(nn.Linear(hc + 1, hc), nn.Tanh())
+        layers = []
+        dims = [hc] * (opt.cde_fn_num_layers + 1) + [hc * (hc + 1)]
+        for i in range(opt.cde_fn_num_layers + 1):
+            layers += [nn.Linear(dims[i], dims[i + 1]), nn.Identity()]
+        self.cde_func = nn.Module()
+        self.cde_func.net = nn.Sequential(*layers)
+        self.regressor = nn.Sequential(nn.Linear(hc, 128), nn.LeakyReLU(0.1), nn.Linear(128, 6))
+        self.history = None  # eval-mode observations of the windows so far (PoseCDE.py:88-92)
+
+    def get_reduction_net_params(self):
+        return self.reduction_net.parameters()
+
+    def get_regressor_params(self):
+        return self.regressor.parameters()
+
+    def get_other_params(self):
+        return [p for n, p in self.named_parameters() if not n.startswith("regressor")]
+
+
 class DeepVIO(nn.Module):
     def __init__(self, opt, seed=None):
         super().__init__()
         if opt.model_type == "ltc":
             raise NotImplementedError("LTC model not implemented yet")
-        if opt.model_type in ("cde", "rde"):
-            raise NotImplementedError(f"model_type {opt.model_type!r}: the Neural-CDE path is not built yet (DESIGN.md section 9)")
-        if opt.model_type not in ("ode-rnn", "rnn"):
+        if opt.model_type == "rde":
+            raise NotImplementedError("model_type 'rde': PoseRDE is experimental and broken upstream (out of scope, SURVEY.md section 2)")
+        if opt.model_type not in ("ode-rnn", "rnn", "cde"):
             raise ValueError(f"model_type {opt.model_type!r} not supported")
         if opt.fuse_method not in ("cat", "soft", "hard"):
             raise ValueError(f"fuse_method {opt.fuse_method!r} not supported")
@@ -110,7 +144,12 @@ class DeepVIO(nn.Module):
         self.opt = opt
         self.Image_net = _ImageNet(opt)
         self.Inertial_net = _InertialNet(opt)
-        self.Pose_net = _PoseNet(opt, with_ode=(opt.model_type == "ode-rnn"))
+        if opt.model_type == "cde":
+            if opt.fuse_method == "hard":
+                raise ValueError("fuse_method 'hard' is not supported on the Neural-CDE path")
+            self.Pose_net = _PoseCDENet(opt)
+        else:
+            self.Pose_net = _PoseNet(opt, with_ode=(opt.model_type == "ode-rnn"))
         self._plan = None
         self._plan_sig = None
         self._lib = _lib.load()  # raises if the HIP library is missing: no silent fallback
@@ -147,6 +186,9 @@ class DeepVIO(nn.Module):
         # torchode IntegralController(atol=1e-6, rtol=1e-2), dt0 = 1e-4 (PoseODERNN.py:57,72)
         c.atol, c.rtol, c.dt0 = getattr(o, "ode_atol", 1e-6), getattr(o, "ode_rtol", 1e-2), getattr(o, "ode_dt0", 1e-4)
         c.max_steps = getattr(o, "ode_max_steps", 200000)
+        c.cde_hidden_dim, c.cde_fn_num_layers = o.cde_hidden_dim, o.cde_fn_num_layers
+        c.cde_activation = _lib.ACTIVATIONS.get(o.cde_activation_fn, 0)
+        c.cde_solver = _lib.SOLVERS.get(o.cde_solver, 0)
         return c
 
     def _ensure_plan(self):
@@ -198,6 +240,8 @@ class DeepVIO(nn.Module):
     def forward(self, img, imu, timestamps, hc=None):
         """img [B,S,3,H,W], imu [B,10(S-1)+1(+tail),6], timestamps [B,S], hc None | [L,B,F] -> (poses [B,S-1,6], h_T [L,B,F])."""
         self._ensure_plan()
+        if self.opt.model_type == "cde":
+            return self.pose_cde(self.image_encoder(img), self.imu_encoder(imu), timestamps, hc)
         if self.opt.fuse_method == "hard":
             fv, fi = self.image_encoder(img), self.imu_encoder(imu)
             return self.pose_net(fv, fi, timestamps, hc)
@@ -299,6 +343,42 @@ class DeepVIO(nn.Module):
         _lib.check(self._lib.odevio_ode_rnn_fwd(self._plan, fused.data_ptr(), ts.data_ptr(), hcp, B, P, poses.data_ptr(),
                                                 h_T.data_ptr(), stats.data_ptr(), self._stream()))
         return (poses, h_T, stats) if return_stats else (poses, h_T)
+
+    def pose_cde(self, fv, fi, timestamps, prev=None, return_stats=False):
+        """PoseCDE.forward (reference PoseCDE.py:76-103) on encoder features.
+
+        Host side (plumbing only): time-channel concat and the eval-mode window history; everything else - z0, the
+        control-path derivative, CDEFunc, the solver, the regressor - runs in libodevio.  Like the reference, eval mode
+        uses raw timestamps and accumulates history when ``prev`` is given, the output times are ROW 0's timestamps,
+        and the INITIAL state z0 is what is returned as the second value.
+        """
+        self._ensure_plan()
+        net = self.Pose_net
+        fused = self.fuse(fv, fi)
+        ts = self._dev(timestamps, "timestamps")
+        tsd = ts - ts[:, :1] if self.training else ts
+        x = torch.cat([tsd[:, 1:, None], fused], dim=-1)
+        if not self.training:
+            net.history = torch.cat([net.history, x], dim=1) if prev is not None else x
+            obs = net.history
+        else:
+            net.history = None
+            obs = x
+        obs = obs.contiguous()
+        B, L, C = obs.shape
+        t_out = tsd[0, 1:].double().cpu().contiguous()
+        n_out = t_out.numel()
+        hc = self.opt.cde_hidden_dim
+        z0_in = None
+        if prev is not None:
+            prev = self._dev(prev, "hc")
+            z0_in = prev.data_ptr()
+        poses = torch.empty(B, n_out, 6, device=obs.device, dtype=torch.float32)
+        z0 = torch.empty(B, hc, device=obs.device, dtype=torch.float32)
+        stats = (ctypes.c_int32 * 2)()
+        _lib.check(self._lib.odevio_cde_fwd(self._plan, obs.data_ptr(), B, L, t_out.data_ptr(), n_out, z0_in, poses.data_ptr(),
+                                            z0.data_ptr(), ctypes.cast(stats, ctypes.c_void_p), self._stream()))
+        return (poses, z0, (int(stats[0]), int(stats[1]))) if return_stats else (poses, z0)
 
     STAGES = ("conv1", "conv2_6", "visual_head", "imu_fuse", "integrator", "regressor")
 

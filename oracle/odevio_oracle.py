@@ -392,3 +392,198 @@ def rel_err(a, b):
     """max|a-b| / max|b| - the tensor-scale relative error used for the 1e-4 parity bar."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# ----------------------------------------------------------------------------------------------
+# Neural-CDE path (PoseCDE.py:76-103) - torchcde 0.2.5 / torchdiffeq 0.2.3 restated (UNPINNED, DESIGN.md 3.5)
+# ----------------------------------------------------------------------------------------------
+DPS_C_MID = [6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+             187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+CDE_ATOL, CDE_RTOL = 1e-6, 1e-4  # PoseCDE.py:101
+
+
+def rectilinear_coeffs(obs):
+    """torchcde.linear_interpolation_coeffs(obs, rectilinear=0): [(t1,x1),(t2,x1),(t2,x2),(t3,x2),...] (2L-1 knots at 0..2L-2)."""
+    B, L, C = obs.shape
+    out = obs.new_empty(B, 2 * L - 1, C)
+    out[:, 0::2] = obs
+    lag = obs[:, :-1].clone()
+    lag[:, :, 0] = obs[:, 1:, 0]
+    out[:, 1::2] = lag
+    return out
+
+
+def control_segment(t_f32, n_knots):
+    """Index of the linear piece torchcde's LinearInterpolation uses at time t (bucketize(t) - 1, clamped)."""
+    idx = int(math.ceil(t_f32)) - 1  # knots are the integers 0..n_knots-1; t on a knot belongs to the piece on its LEFT
+    return max(0, min(idx, n_knots - 2))
+
+
+def cde_field(sd, opt, coeffs, dtype):
+    """f(t, z) = CDEFunc(z).view(B, H, H+1) @ dX/dt(t)   (torchcde _VectorField, ODEFunc.py:81-83)."""
+    Hc = opt.cde_hidden_dim
+
+    def f(t_f32, z):
+        i = control_segment(t_f32, coeffs.shape[1])
+        g = coeffs[:, i + 1] - coeffs[:, i]  # knot spacing 1
+        vf = mlp_tanh_out(sd, "Pose_net.cde_func.net", opt.cde_fn_num_layers, z, opt.cde_activation_fn).view(-1, Hc, Hc + 1)
+        return (vf @ g.unsqueeze(-1)).squeeze(-1).to(dtype)
+    return f
+
+
+def _rms(x):
+    return float(x.abs().pow(2).mean().sqrt())
+
+
+def _f32_prev(t):
+    return float(torch.nextafter(torch.tensor(t, dtype=torch.float32), torch.tensor(t - 1.0, dtype=torch.float32)))
+
+
+def _f32_next(t):
+    return float(torch.nextafter(torch.tensor(t, dtype=torch.float32), torch.tensor(t + 1.0, dtype=torch.float32)))
+
+
+def odeint_dopri5(f, y0, ts, jump_t, rtol=CDE_RTOL, atol=CDE_ATOL, trace=None):
+    """torchdiffeq 0.2.3 odeint(method='dopri5') with a `jump_t` option, restated: ONE shared step size for the whole
+    batch (RMS norm over every element), Hairer initial step, 4th-order dense output at the requested times, steps
+    clipped at the jump points where f is re-evaluated on the far side.  Time is float64, the state `y0.dtype`;
+    f receives time as float32 (torchdiffeq casts it to the state's dtype), perturbed one ulp backwards at a step end."""
+    tab = DOPRI5
+    f32 = lambda t: float(torch.tensor(t, dtype=torch.float32))
+    t0 = float(ts[0])
+    fy0 = f(f32(t0), y0)
+    # _select_initial_step(order = 4)
+    scale = atol + y0.abs() * rtol
+    d0, d1 = _rms(y0 / scale), _rms(fy0 / scale)
+    h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    h0 = float(torch.tensor(h0, dtype=y0.dtype))
+    y1 = y0 + h0 * fy0
+    f1 = f(f32(f32(t0) + h0), y1)
+    d2 = abs(_rms((f1 - fy0) / scale) / h0)
+    if d1 <= 1e-15 and d2 <= 1e-15:
+        h1 = max(1e-6, h0 * 1e-3)
+    else:
+        h1 = float(torch.tensor(0.01 / max(d1, d2), dtype=y0.dtype) ** (1.0 / 5.0))
+    dt = float(min(100 * h0, h1))
+    jumps = sorted(j for j in jump_t if j > t0)
+    ji = 0
+    y, fy, tcur, tprev = y0, fy0, t0, t0
+    interp = [y0] * 5
+    out = [y0]
+    n_steps = n_acc = 0
+    for target in [float(t) for t in ts[1:]]:
+        while target > tcur:
+            n_steps += 1
+            if n_steps > MAX_STEPS:
+                raise RuntimeError("odeint_dopri5: step budget exhausted")
+            step = dt
+            t1 = tcur + step
+            on_jump = False
+            if jumps and tcur < jumps[ji] < tcur + step:
+                on_jump = True
+                t1 = jumps[ji]
+                step = t1 - tcur
+            dtf = float(torch.tensor(step, dtype=y0.dtype))
+            ks = [fy]
+            for i in range(1, 7):
+                acc = None
+                for j, aij in enumerate(tab.a[i]):
+                    term = ks[j] * (aij * dtf)
+                    acc = term if acc is None else acc + term
+                ti = _f32_prev(f32(t1)) if i == 6 else f32(f32(tcur) + (sum(tab.a[i])) * dtf)  # alpha_i = sum of row i
+                ks.append(f(ti, y + acc))
+                if i == 6:
+                    y1 = y + acc  # FSAL: the last stage is evaluated at y1
+            err = None
+            for j, ej in enumerate(tab.b_err):
+                term = ks[j] * (ej * dtf)
+                err = term if err is None else err + term
+            tol = atol + rtol * torch.maximum(y.abs(), y1.abs())
+            ratio = _rms(err / tol)
+            accept = ratio <= 1.0
+            if trace is not None:
+                trace.setdefault("steps", []).append((tcur, step, accept))
+            if accept:
+                n_acc += 1
+                ymid = None
+                for j, mj in enumerate(DPS_C_MID):
+                    term = ks[j] * (mj * dtf)
+                    ymid = term if ymid is None else ymid + term
+                ymid = y + ymid
+                fa, fb = ks[0], ks[6]
+                interp = [y, dtf * fa, dtf * (fb - 4 * fa) - 11 * y - 5 * y1 + 16 * ymid,
+                          dtf * (5 * fa - 3 * fb) + 18 * y + 14 * y1 - 32 * ymid,
+                          2 * dtf * (fb - fa) - 8 * (y1 + y) + 16 * ymid]
+                tprev, tcur, y, fy = tcur, t1, y1, ks[6]
+                if on_jump:
+                    if ji != len(jumps) - 1:
+                        ji += 1
+                    fy = f(_f32_next(f32(tcur)), y)  # the far side of the discontinuity
+            # _optimal_step_size
+            if ratio == 0:
+                factor = 10.0
+            else:
+                dfac = 1.0 if ratio < 1 else 0.2
+                factor = min(10.0, max(0.9 / ratio ** 0.2, dfac))
+            dt = step * factor
+        x = float(torch.tensor((target - tprev) / (tcur - tprev), dtype=y0.dtype))
+        total, xp = interp[0] + x * interp[1], x
+        for cf in interp[2:]:
+            xp = xp * x
+            total = total + xp * cf
+        out.append(total)
+    if trace is not None:
+        trace["n_steps"], trace["n_accepted"] = n_steps, n_acc
+    return torch.stack(out, 0)
+
+
+def odeint_fixed(f, y0, ts, method):
+    """torchdiffeq fixed-grid solvers with the output times as the grid (step_size=None): euler, rk4 (3/8 rule)."""
+    f32 = lambda t: float(torch.tensor(t, dtype=torch.float32))
+    out, y = [y0], y0
+    for a, b in zip(ts[:-1], ts[1:]):
+        t0, t1 = float(a), float(b)
+        dt = float(torch.tensor(t1 - t0, dtype=y0.dtype))
+        k1 = f(f32(t0), y)
+        if method == "euler":
+            y = y + dt * k1
+        else:
+            k2 = f(f32(t0 + dt / 3), y + dt * k1 / 3)
+            k3 = f(f32(t0 + dt * 2 / 3), y + dt * (k2 - k1 / 3))
+            k4 = f(_f32_prev(f32(t1)), y + dt * (k1 - k2 + k3))
+            y = y + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        out.append(y)
+    return torch.stack(out, 0)
+
+
+def pose_cde(sd, fv, fi, ts, prev, history, opt, dtype=torch.float32, training=False, trace=None):
+    """PoseCDE.forward (PoseCDE.py:76-103).  Returns (poses [B,P,6], z0 [B,H], new history).
+
+    Faithful to the reference, including its quirks: eval mode uses the raw timestamps (:81), the control path's knots
+    are the integers 0..2L-2 while the integration runs over the real times `ts[0, 1:]` of ROW 0 (:101), the first
+    output is z0 itself, and z0 (not the final state) is returned (:103).  `reduction_net` is never applied (:53-58).
+    """
+    sd = _sd(sd, dtype)
+    fused = fuse(sd, fv, fi, opt.fuse_method, dtype)
+    ts = ts.to(dtype)
+    tsd = ts - ts[:, :1] if training else ts
+    x = torch.cat([tsd[:, 1:, None], fused], dim=-1)
+    if not training:
+        history = torch.cat([history, x], dim=1) if prev is not None else x
+        obs = history
+    else:
+        history, obs = None, x
+    coeffs = rectilinear_coeffs(obs)
+    if prev is None:
+        z0 = torch.tanh(F_.linear(coeffs[:, 0], sd["Pose_net.initial.0.weight"], sd["Pose_net.initial.0.bias"]))
+    else:
+        z0 = prev.to(dtype)
+    f = cde_field(sd, opt, coeffs, dtype)
+    tt = [float(v) for v in tsd[0, 1:]]
+    if opt.cde_solver == "dopri5":
+        zs = odeint_dopri5(f, z0, tt, jump_t=[float(k) for k in range(coeffs.shape[1])], trace=trace)
+    elif opt.cde_solver in ("euler", "rk4", "runge_kutta"):
+        zs = odeint_fixed(f, z0, tt, "euler" if opt.cde_solver == "euler" else "rk4")
+    else:
+        raise ValueError(f"Solver {opt.cde_solver} not supported")
+    return regressor(sd, zs.transpose(0, 1)), z0, history

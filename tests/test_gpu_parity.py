@@ -251,6 +251,48 @@ def test_pose_ode_rnn(dev, cfg, B, drop):
 
 
 # ------------------------------------------------------------------------------------------------
+# Neural-CDE path
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [dict(), dict(cde_solver="rk4"), dict(cde_solver="euler"),
+                                 dict(cde_activation_fn="softplus", cde_fn_num_layers=2, fuse_method="soft")])
+@pytest.mark.parametrize("training", [True, False])
+def test_pose_cde(dev, cfg, training):
+    """PoseCDE.forward on encoder features: training mode (relative time) and eval mode (raw time, carried history)."""
+    opt = default_opt(img_h=64, img_w=128, model_type="cde", cde_hidden_dim=128, v_f_len=96, i_f_len=32, **cfg)
+    model, sd = make_model(opt, seed=61)
+    model.train(training)
+    B = 5
+    g = torch.Generator().manual_seed(3)
+    fv, fi = torch.randn(B, 10, 96, generator=g), torch.randn(B, 10, 32, generator=g)
+    ts = synth.timestamps(B, 11, drop=0.3, seed=4) + (0.0 if training else 3.0)
+    poses, z0, (n_steps, n_acc) = model.pose_cde(fv.cuda(), fi.cuda(), ts.cuda(), None, return_stats=True)
+    tr = {}
+    ref_p, ref_z0, hist = oc.pose_cde(sd, fv, fi, ts, None, None, opt, training=training, trace=tr)
+    assert_close(z0, ref_z0, what="z0")
+    assert_close(poses, ref_p, what="poses")
+    if opt.cde_solver == "dopri5":
+        assert (n_steps, n_acc) == (tr["n_steps"], tr["n_accepted"])
+    if not training:  # second window: carried state + history (reference KITTI_eval.py:141 with PoseCDE)
+        p2, z2 = model.pose_cde(fv.flip(0).cuda(), fi.flip(0).cuda(), (ts + 1.0).cuda(), z0)
+        r2, rz2, _ = oc.pose_cde(sd, fv.flip(0), fi.flip(0), ts + 1.0, ref_z0, hist, opt)
+        assert_close(p2, r2, tol=2e-4, what="poses (window 2)")
+        assert model.Pose_net.history.shape == (B, 20, 129)
+    model.eval()
+
+
+def test_deepvio_forward_cde(dev):
+    opt = default_opt(img_h=64, img_w=128, model_type="cde", cde_hidden_dim=128, v_f_len=96, i_f_len=32)
+    model, sd = make_model(opt, seed=62)
+    img, imu, ts = synth.batch(2, 5, 64, 128, seed=12)
+    poses, z0 = model(img.cuda(), imu.cuda(), (ts + 2.0).cuda())
+    fv, fi = oc.image_encoder(sd, img), oc.inertial_encoder(sd, imu)
+    ref_p, ref_z0, _ = oc.pose_cde(sd, fv, fi, ts + 2.0, None, None, opt)
+    assert poses.shape == (2, 4, 6) and z0.shape == (2, 128)
+    assert_close(poses, ref_p, what="poses")
+    assert_close(z0, ref_z0, what="z0")
+
+
+# ------------------------------------------------------------------------------------------------
 # whole path
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("solver", ["rk4", "dopri5"])
