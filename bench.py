@@ -71,21 +71,31 @@ def cpu_baseline(opt, sd, budget_s=20.0):
             if time.perf_counter() - t0 > budget_s or reps >= 8:
                 break
         dt = (time.perf_counter() - t0) / reps
-        # bare RK4 step loop of the [32,768] state (the "integrator steps/s" half of the metric)
+        # bare RK4 step loop of the [32,768] state (the "integrator steps/s" half of the metric).  32-row GEMMs do not
+        # scale to every host core (oversubscription makes them slower), so try a few thread counts and keep the best.
         F = opt.v_f_len + opt.i_f_len
-        y = torch.randn(2 * B, F) * 0.5
         f = lambda v: oc.ode_func(sd, v, opt.ode_fn_num_layers, opt.ode_activation_fn)
         h = torch.full((2 * B,), 0.1)
-        oc.rk_stages(f, oc.RK4_38, y, h)
-        t1 = time.perf_counter()
-        n = 200
-        for _ in range(n):
-            y, _, _ = oc.rk_stages(f, oc.RK4_38, y, h)
-        step_s = (time.perf_counter() - t1) / n
-    return {"value": nb * S / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        all_threads = torch.get_num_threads()
+        best = (0.0, all_threads)
+        n = 100
+        for nt in sorted({1, 4, 8, 16, all_threads}):
+            if nt > all_threads:
+                continue
+            torch.set_num_threads(nt)
+            y = torch.randn(2 * B, F, generator=torch.Generator().manual_seed(0)) * 0.5
+            oc.rk_stages(f, oc.RK4_38, y, h)
+            t1 = time.perf_counter()
+            for _ in range(n):
+                y, _, _ = oc.rk_stages(f, oc.RK4_38, y, h)
+            rate = n / (time.perf_counter() - t1)
+            if rate > best[0]:
+                best = (rate, nt)
+        torch.set_num_threads(all_threads)
+    return {"value": nb * S / dt, "unit": "frames/s", "cores": all_threads, "kind": "port",
             "sample": f"oracle DeepVIO.forward, {nb} sequence x {S} frames 256x512 fp32, {reps} reps, {dt:.2f} s each",
-            "integrator_steps_per_s": 1.0 / step_s,
-            "integrator_sample": f"{n} RK4 (3/8) steps of the [32,768] state through ODEFunc(768-512-512-512-768)"}
+            "integrator_steps_per_s": best[0], "integrator_cores": best[1],
+            "integrator_sample": f"{n} RK4 (3/8) steps of the [32,768] state through ODEFunc(768-512-512-512-768), best of 1/4/8/16/all threads"}
 
 
 def main():

@@ -1,6 +1,7 @@
 """Diagnostic: phase shares of the persistent integrator (needs libodevio_stamps.so; GPU box only)."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes, os, sys
-os.environ["ODEVIO_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "odevio_amd", "libodevio_stamps.so")
+os.environ["ODEVIO_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "odevio_amd", "libodevio_stamps.so")
 import torch
 from odevio_amd import DeepVIO, default_opt, synth, _lib
 for solver, B, safe in (("rk4", 16, "0"), ("rk4", 16, "1"), ("dopri5", 16, "0"), ("rk4", 1, "0")):

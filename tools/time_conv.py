@@ -1,4 +1,5 @@
 """Times single conv blocks (production kernels) at the bench shapes; GPU box only.  ODEVIO_LIB selects a build."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, torch
 from odevio_amd import DeepVIO, default_opt, weights
 opt = default_opt()

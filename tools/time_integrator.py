@@ -1,4 +1,5 @@
 """Times the production integrator (pose_net on features) with events; GPU box only."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from odevio_amd import DeepVIO, default_opt, synth
 for solver, B, extra in (("rk4", 16, {}), ("dopri5", 16, {}), ("rk4", 1, {}), ("rk4", 26, {}), ("rk4", 16, dict(ode_substeps=4))):
