@@ -422,13 +422,27 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K factor from a small cost model.  The chip runs 512 workgroups of this kernel at a time (2 per CU); a layer
+// whose tile count is not a multiple of that leaves CUs idle in its last round (conv5: 640 tiles = 1.25 rounds,
+// conv6: 320 = 0.6).  Splitting K multiplies the workgroups and shortens each; the price is the fp32 slab round trip
+// of the deterministic combine.  Units: microseconds, with ~4.1 us per K-tile step of a CU running two workgroups.
 static int pick_splitk(int M, int N, int nk) {
-  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  if (tiles >= 192 || nk < 8) return 1;
-  int s = (256 + tiles - 1) / tiles;
-  s = std::min(s, nk / 4);
-  s = std::min(s, 64);
-  return std::max(s, 1);
+  const double tiles = (double)((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles >= 2048 || nk < 8) return 1;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64}) {
+    if (s > 1 && nk / s < 8) break;
+    const double rounds = std::ceil(tiles * s / 512.0);
+    const double steps = std::ceil((double)nk / s) + 3.0;  // + prologue / epilogue of a workgroup
+    double cost = rounds * steps * 4.1;
+    if (s > 1) cost += (s + 1.0) * M * N * 4.0 / 4.0e6 + 8.0;  // slab write + read at ~4 TB/s, one more launch
+    if (cost < best_cost * 0.97) {  // prefer the smaller factor unless the gain is real
+      best_cost = cost;
+      best = s;
+    }
+  }
+  return best;
 }
 
 static int run_gemm(odevio_plan* p, const float* in, int M, int K, const float* W, int N, const float* scale,
