@@ -57,6 +57,18 @@ def ode_bytes_per_rk4_step(opt, rows):
     return 4 * params * 4 + 2 * rows * F * 4
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per forward of one kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
+    in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_summary.py).
+    Counters cannot be read from inside the timed run, so this is the last profiled value, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        k = json.load(open(path))["kernels"][kernel_key]
+        return int(k["fetch_bytes"] + k["write_bytes"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(opt, sd, budget_s=20.0):
     from oracle import odevio_oracle as oc  # the oracle is the CPU baseline leg, nothing else
     nb = 1
@@ -184,10 +196,11 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"kernel": "conv_igemm_kernel (conv2..conv6)", "bound": "mfma", "achieved": round(conv_tflops, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None},
+                         "traffic": pmc_traffic("conv_igemm_kernel [dispatches > 0.4 ms]"),
+                         "traffic_note": "HBM bytes per forward (8 conv launches) from profiles/r01_pmc_traffic.json; algorithmic activations in+out = 4.9e9"},
             "roofline_integrator": {"kernel": "integrator_kernel", "bound": "hbm",
                                     "achieved": round(integ_bytes / integ_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(integ_bytes / integ_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                                    "frac": round(integ_bytes / integ_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("integrator_kernel<4>"),
                                     "note": "latency-bound by design: weights stay in LDS, algorithmic bytes assume a re-read per stage"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -29,8 +29,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order (speed only).  Workgroups are dealt round-robin to the 8 XCDs in launch order, so with the
+  // plain (x, y) -> (M tile, N tile) map an XCD gets M tiles 8 apart (no shared halo rows) and the N tiles of one
+  // M tile run far apart in time: the PMC pass showed ~10x the algorithmic bytes crossing the fabric.  Here every
+  // XCD owns a CONTIGUOUS range of M tiles and walks it N-tile-fastest, so the workgroups that share an activation
+  // panel (all N tiles of an M tile, and the neighbouring M tiles with their halo) are co-resident on one L2.
+  // gridDim.x is padded to a multiple of 8 by the launcher; the map is a bijection onto [0, chunk*8) x [0, NT).
+  const int NT = gridDim.y;
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int chunk = gridDim.x >> 3;                   // M tiles per XCD
+  const int mt_idx = xcd * chunk + slot / NT;
+  const int nt_idx = slot - (slot / NT) * NT;
+  if (mt_idx * BM >= a.M) return;                     // padding tiles
+  const int m0 = mt_idx * BM;
+  const int n0 = nt_idx * BN;
 
   // ---- loader role: rows lrow + 32q, one float4 at column lc4*4
   const int lrow = tid >> 3;
@@ -60,8 +73,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     b_row[q] = (n < a.Cout) ? a.w + (size_t)n * taps * a.Cin + lc4 : nullptr;
   }
 
-  const int cpt = a.Cin / BK;  // cin chunks per tap
-  const int nk = taps * cpt;
+  const int nk = taps * (a.Cin / BK);  // K-tiles: (cin chunk, tap)
   int kt_begin = 0, kt_end = nk;
   if (a.splitk > 1) {
     kt_begin = blockIdx.z * a.ktiles_per_split;
@@ -70,28 +82,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   f32x4 ra[4], rb[4];
   // K-tile coordinates (workgroup-uniform scalars): tap (kh, kw), offset of the tap+chunk inside a pixel row / a filter
+  // K order: cin-chunk MAJOR, filter tap MINOR.  For one 32-channel chunk the kh*kw taps re-read the same few KB
+  // of activations shifted by a pixel, back to back, so they hit in L1/L2.  (Tap-major order makes every tap sweep
+  // the workgroup's whole 128-pixel x Cin slab - 256 KB per workgroup, 16 MB per XCD in flight.)
   int t_kh = 0, t_kw = 0, t_cc = 0, t_aoff = 0, t_boff = 0;
   auto set_tile = [&](int kt) {  // once, for the first tile of this workgroup
-    const int tap = kt / cpt;
-    t_cc = (kt - tap * cpt) * BK;
+    const int chunk_i = kt / taps;
+    const int tap = kt - chunk_i * taps;
+    t_cc = chunk_i * BK;
     t_kh = tap / a.KW;
     t_kw = tap - t_kh * a.KW;
     t_aoff = (t_kh * a.Wi + t_kw) * a.Cin + t_cc;
     t_boff = tap * a.Cin + t_cc;
   };
-  auto next_tile = [&]() {  // advance (kh, kw, cin-chunk) by one K-tile without divisions
-    t_cc += BK;
-    t_aoff += BK;
-    t_boff += BK;  // filter taps are contiguous: tap*Cin + cc simply keeps counting
-    if (t_cc == a.Cin) {
-      t_cc = 0;
-      ++t_kw;
-      t_aoff -= a.Cin;
-      t_aoff += a.Cin;  // next pixel to the right starts exactly Cin floats later
-      if (t_kw == a.KW) {
-        t_kw = 0;
-        ++t_kh;
-        t_aoff += (a.Wi - a.KW) * a.Cin;  // first tap of the next filter row
+  auto next_tile = [&]() {  // advance (cin-chunk, kh, kw) by one K-tile without divisions
+    ++t_kw;
+    t_aoff += a.Cin;  // next pixel to the right
+    t_boff += a.Cin;  // next tap of the filter
+    if (t_kw == a.KW) {
+      t_kw = 0;
+      ++t_kh;
+      t_aoff += (a.Wi - a.KW) * a.Cin;  // first tap of the next filter row
+      if (t_kh == a.KH) {
+        t_kh = 0;
+        t_cc += BK;
+        t_aoff = t_cc;
+        t_boff = t_cc;
       }
     }
   };
@@ -253,7 +269,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
 }
 
 void launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
-  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.splitk > 1 ? a.splitk : 1);
+  const int mt = (a.M + BM - 1) / BM;
+  dim3 grid((mt + 7) / 8 * 8, (a.Cout + BN - 1) / BN, a.splitk > 1 ? a.splitk : 1);  // x padded for the XCD map
   hipLaunchKernelGGL(conv_igemm_kernel, grid, dim3(256), 0, st, a);
   if (a.splitk > 1) {
     const size_t total = (size_t)a.M * a.Cout;
