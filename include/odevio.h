@@ -134,6 +134,17 @@ int odevio_cde_fwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, co
 int odevio_forward(odevio_plan* plan, const float* img, const float* imu, int32_t T, const float* ts,
                    const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream);
 
+/* Trajectory accumulation for the streaming evaluator: path_accu / pose_accu / pose_6DoF_to_matrix of the reference
+ * (src/data/utils.py:93-161, called from kitti_eval, src/data/KITTI_eval.py:231-232).  No plan needed; every pointer is
+ * a DEVICE pointer.  poses6 = relative poses [N,6] (angles x,y,z then translation) of n_drives drives back to back,
+ * float32 (is_f64 = 0) or float64; offsets[n_drives+1] = first pose of every drive (int64); carry = NULL (start every
+ * drive at the identity) or [n_drives,4,4] float64 row-major start poses (the last matrix of the previous window);
+ * mats = [(N + n_drives),4,4] float64: drive d writes offsets[d+1]-offsets[d]+1 matrices starting at row
+ * offsets[d]+d, the first being its start pose.  A float32 input has its per-pose rotation built in float32, as
+ * numpy does for the reference; the running product is float64. */
+int odevio_path_accu(const void* poses6, int32_t is_f64, const int64_t* offsets, int32_t n_drives, const double* carry,
+                     double* mats, void* stream);
+
 /* Per-stage timing of odevio_forward with HIP events recorded on the caller's stream (used by bench.py for
  * the roofline figures).  Stages: 0 conv1, 1 conv2..conv6 (implicit-GEMM kernel), 2 visual head,
  * 3 inertial encoder + fusion, 4 persistent ODE-RNN integrator, 5 pose regressor. */

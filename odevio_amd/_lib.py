@@ -20,6 +20,7 @@ SYMBOLS = [
     "odevio_version", "odevio_last_error", "odevio_plan_create", "odevio_plan_destroy", "odevio_reserve",
     "odevio_check", "odevio_conv_block_fwd", "odevio_image_encoder_fwd", "odevio_imu_encoder_fwd", "odevio_fuse_fwd", "odevio_ode_func",
     "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
+    "odevio_path_accu",
 ]
 
 
@@ -87,6 +88,7 @@ def load():
     lib.odevio_profile_enable.argtypes = [vp, i32]
     lib.odevio_profile_read.argtypes = [vp, fp]
     lib.odevio_debug_stamps.argtypes = [vp, fp, vp]
+    lib.odevio_path_accu.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     for s in SYMBOLS[2:]:
         if s != "odevio_plan_destroy":
             getattr(lib, s).restype = ctypes.c_int

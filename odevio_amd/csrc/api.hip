@@ -758,6 +758,13 @@ extern "C" int odevio_profile_read(odevio_plan* p, float* ms_out) {
   return 0;
 }
 
+extern "C" int odevio_path_accu(const void* poses6, int32_t is_f64, const int64_t* offsets, int32_t n_drives, const double* carry,
+                                double* mats, void* stream) {
+  ARGCHK(poses6 && offsets && mats && n_drives > 0, "odevio_path_accu: bad argument");
+  HIPCHK(launch_path_accu(poses6, is_f64, offsets, n_drives, carry, mats, (hipStream_t)stream));
+  return ODEVIO_OK;
+}
+
 extern "C" int odevio_debug_stamps(odevio_plan* p, uint64_t* out8, void* stream) {
   ARGCHK(p && out8, "odevio_debug_stamps: bad argument");
   HIPCHK(hipMemcpyAsync(out8, p->status + 8, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -25,6 +25,7 @@ struct ConvArgs {
   int act;              // EpilogueAct
   float slope;
   int splitk, ktiles_per_split;
+  int xcd_map;          // set by the launcher: XCD-aware tile order (>= 16 M tiles)
 };
 
 // conv1 of the FlowNetS stack, reading frame pairs in place from img [B][S][3][H][W]
@@ -54,6 +55,9 @@ struct ImuArgs {
 void launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 void launch_conv1(const Conv1Args& a, int n_cu, hipStream_t st);
 void launch_imu_convs(const ImuArgs& a, hipStream_t st);
+// pose.hip: relative 6-DoF poses -> global 4x4 matrices, one workgroup per drive (all pointers on the device)
+hipError_t launch_path_accu(const void* poses, int is_f64, const int64_t* offsets_dev, int n_drives, const double* carry,
+                            double* out, hipStream_t stream);
 
 __device__ __forceinline__ float apply_epi(float v, int act, float slope) {
   if (act == EPI_LEAKY) return v > 0.f ? v : v * slope;

@@ -34,13 +34,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // M tile run far apart in time: the PMC pass showed ~10x the algorithmic bytes crossing the fabric.  Here every
   // XCD owns a CONTIGUOUS range of M tiles and walks it N-tile-fastest, so the workgroups that share an activation
   // panel (all N tiles of an M tile, and the neighbouring M tiles with their halo) are co-resident on one L2.
-  // gridDim.x is padded to a multiple of 8 by the launcher; the map is a bijection onto [0, chunk*8) x [0, NT).
+  // For >= 16 M tiles the launcher pads gridDim.x to a multiple of 8; the map is then a bijection onto
+  // [0, chunk*8) x [0, NT).  Fewer M tiles (the linear layers: M = frame pairs) keep the plain map - the padded one
+  // would leave most XCDs without work.
   const int NT = gridDim.y;
-  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xcd = lin & 7, slot = lin >> 3;
-  const int chunk = gridDim.x >> 3;                   // M tiles per XCD
-  const int mt_idx = xcd * chunk + slot / NT;
-  const int nt_idx = slot - (slot / NT) * NT;
+  int mt_idx = blockIdx.x, nt_idx = blockIdx.y;
+  if (a.xcd_map) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int chunk = gridDim.x >> 3;                 // M tiles per XCD
+    mt_idx = xcd * chunk + slot / NT;
+    nt_idx = slot - (slot / NT) * NT;
+  }
   if (mt_idx * BM >= a.M) return;                     // padding tiles
   const int m0 = mt_idx * BM;
   const int n0 = nt_idx * BN;
@@ -268,9 +273,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
   }
 }
 
-void launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
+void launch_conv_igemm(const ConvArgs& a_in, hipStream_t st) {
+  ConvArgs a = a_in;
   const int mt = (a.M + BM - 1) / BM;
-  dim3 grid((mt + 7) / 8 * 8, (a.Cout + BN - 1) / BN, a.splitk > 1 ? a.splitk : 1);  // x padded for the XCD map
+  a.xcd_map = mt >= 16;
+  dim3 grid(a.xcd_map ? (mt + 7) / 8 * 8 : mt, (a.Cout + BN - 1) / BN, a.splitk > 1 ? a.splitk : 1);  // x padded for the XCD map
   hipLaunchKernelGGL(conv_igemm_kernel, grid, dim3(256), 0, st, a);
   if (a.splitk > 1) {
     const size_t total = (size_t)a.M * a.Cout;

@@ -55,3 +55,34 @@ def timestamps(B, S, drop=0.0, seed=0, absolute=False):
 
 def batch(B, S=11, H=256, W=512, drop=0.0, seed=0):
     return images(B, S, H, W, seed), imu(B, S, seed), timestamps(B, S, drop, seed)
+
+
+def trajectory(n_frames, seed=0, noise=0.0):
+    """Car-like relative poses [n_frames-1, 6] float64 in the reference's convention (angles x,y,z then translation,
+    camera z forward; src/data/utils.py:44-69): ~1 m per frame forward with slowly varying yaw about y and small
+    roll/pitch/side-slip.  `noise` adds an estimation error (a biased, noisy copy) - a stand-in for network output."""
+    rng = np.random.default_rng(seed)
+    n = n_frames - 1
+    yaw_rate = 0.02 * np.sin(np.arange(n) / 37.0 + rng.uniform(0, 6)) + 0.004 * rng.standard_normal(n)
+    p = np.zeros((n, 6))
+    p[:, 0] = 0.002 * rng.standard_normal(n)
+    p[:, 1] = yaw_rate
+    p[:, 2] = 0.002 * rng.standard_normal(n)
+    p[:, 3] = 0.01 * rng.standard_normal(n)
+    p[:, 4] = 0.01 * rng.standard_normal(n)
+    p[:, 5] = 1.0 + 0.3 * np.sin(np.arange(n) / 91.0) + 0.02 * rng.standard_normal(n)
+    if noise:
+        p = p * (1.0 + noise) + noise * 0.05 * rng.standard_normal(p.shape) * np.array([0.02, 0.02, 0.02, 1, 1, 1])
+    return p
+
+
+def drive(n_frames, H=256, W=512, seed=0, t0=0.0):
+    """One synthetic drive for the streaming evaluator: (frames [N,3,H,W], imus [10(N-1)+1,6], timestamps [N] absolute
+    seconds at ~10 Hz with jitter, poses_rel [N-1,6])."""
+    frames = images(1, n_frames, H, W, seed)[0]
+    g = _gen(seed + 7)
+    z = torch.randn((10 * (n_frames - 1) + 1, 6), generator=g, dtype=torch.float32)
+    imus = z * torch.tensor(IMU_STD) + torch.tensor(IMU_MEAN)
+    rng = np.random.default_rng(seed + 13)
+    ts = t0 + np.concatenate(([0.0], np.cumsum(0.1 + 0.004 * rng.standard_normal(n_frames - 1))))
+    return frames, imus, torch.from_numpy(ts.astype(np.float32)), trajectory(n_frames, seed)

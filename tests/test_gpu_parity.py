@@ -350,3 +350,95 @@ def test_errors_are_loud(dev):
         model(torch.zeros(1, 2, 3, 64, 128), torch.zeros(1, 11, 6), torch.zeros(1, 2))  # CPU tensors: no CPU path
     with pytest.raises(ValueError):
         model(torch.zeros(1, 3, 3, 64, 128).cuda(), torch.zeros(1, 11, 6).cuda(), torch.zeros(1, 3).cuda())  # imu too short
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming evaluator: device pose accumulation, hidden-state carry over windows, KITTI metrics
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 7, 255, 256, 257, 1000, 4540])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_path_accu_matches_oracle(dev, n, dtype):
+    """Scan on the device vs the reference's sequential product; float64, so 1e-9 of the trajectory extent."""
+    from odevio_amd import metrics
+    from oracle import kitti_metrics as om
+    poses = torch.from_numpy(synth.trajectory(n + 1, seed=n)).to(dtype)
+    got = metrics.path_accu(poses.cuda()).cpu().numpy()
+    ref = np.stack(om.path_accu(poses.numpy()))
+    assert got.shape == (n + 1, 4, 4)
+    scale = max(1.0, np.abs(ref[:, :3, 3]).max())
+    # float32 input: device and numpy sinf/cosf may differ in the last bit of a factor, which the product carries along
+    tol = 1e-9 if dtype == torch.float64 else 2e-6
+    assert np.abs(got - ref).max() / scale < tol
+    np.testing.assert_array_equal(got[:, 3], np.tile([0.0, 0.0, 0.0, 1.0], (n + 1, 1)))
+
+
+def test_path_accu_carry_and_many_drives(dev):
+    from odevio_amd import metrics
+    from oracle import kitti_metrics as om
+    lens = [300, 1, 777, 64]
+    poses = [synth.trajectory(n + 1, seed=30 + i) for i, n in enumerate(lens)]
+    cat = torch.from_numpy(np.concatenate(poses)).cuda()
+    off = np.concatenate(([0], np.cumsum(lens)))
+    got = metrics.path_accu(cat, offsets=off).cpu().numpy()
+    pos = 0
+    for p, n in zip(poses, lens):
+        ref = np.stack(om.path_accu(p))
+        assert np.abs(got[pos:pos + n + 1] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+        pos += n + 1
+    # streaming: windows chained through the carry equal one pass over the drive
+    p = torch.from_numpy(poses[2]).cuda()
+    whole = metrics.path_accu(p)
+    carry, parts = None, []
+    for a in range(0, 777, 10):
+        m = metrics.path_accu(p[a:a + 10], carry=carry)
+        carry = m[-1:]
+        parts.append(m[1:] if a else m)
+    assert (torch.cat(parts) - whole).abs().max().item() < 1e-9 * whole.abs().max().item()
+    with pytest.raises(ValueError):
+        metrics.path_accu(p.cpu())
+    with pytest.raises(ValueError):
+        metrics.path_accu(p, offsets=[0, 5])
+
+
+def test_kitti_eval_matches_oracle(dev):
+    from odevio_amd import metrics
+    from oracle import kitti_metrics as om
+    gt = synth.trajectory(1500, seed=3)
+    est = synth.trajectory(1500, seed=3, noise=0.04).astype(np.float32)
+    est_m, gt_m, t_rel, r_rel, t_rmse, r_rmse, usage, speed = metrics.kitti_eval(est, None, gt)
+    ref = om.kitti_eval(est, gt)
+    assert t_rel == pytest.approx(ref["t_rel"], rel=1e-4) and r_rel == pytest.approx(ref["r_rel"], rel=1e-4)
+    assert t_rmse == pytest.approx(ref["t_rmse"], rel=1e-12) and r_rmse == pytest.approx(ref["r_rmse"], rel=1e-12)
+    assert t_rel > 1.0 and usage == 0
+    np.testing.assert_allclose(speed, ref["speed"], rtol=1e-9)
+    assert np.abs(gt_m - np.stack(ref["gt_mats"])).max() < 1e-8
+
+
+@pytest.mark.parametrize("model_type,solver", [("ode-rnn", "rk4"), ("ode-rnn", "dopri5"), ("rnn", "rk4")])
+def test_stream_windows_carry_hidden_state(dev, model_type, solver):
+    """Whole drives streamed window by window (stride S-1, short last window, absolute timestamps, hc carried):
+    three drives of different lengths in lock-step == the oracle walking each drive alone like the reference's
+    test_one_path (KITTI_eval.py:124-160)."""
+    from odevio_amd import stream
+    H, W, S = 64, 128, 5
+    opt = default_opt(img_h=H, img_w=W, ode_solver=solver, model_type=model_type, seq_len=S)
+    model, sd = make_model(opt, seed=61)
+    drives = []
+    for i, n in enumerate([14, 9, 6]):          # 4 windows (last of 2 frames), 2 windows (5+5), 2 windows (5+2)
+        fr, im, ts, gt = synth.drive(n, H, W, seed=70 + i, t0=100.0 * (i + 1))
+        drives.append(stream.Drive(fr, im, ts, gt, name=f"d{i}"))
+    tester = stream.StreamTester(S)
+    est = tester.test_paths(model, drives)
+    model.check()
+    for d, e in zip(drives, est):
+        n = d.frames.shape[0]
+        assert e.shape == (n - 1, 6)
+        hc, ref = None, []
+        for a, b in stream.partition(n, S):
+            lo, hi = stream.imu_rows(a, b)
+            p, hc = oc.deepvio_forward(sd, d.frames[a:b][None], d.imus[lo:hi][None], d.timestamps[a:b][None], hc, opt)
+            ref.append(p[0])
+        assert_close(torch.from_numpy(e), torch.cat(ref), tol=2e-4 if solver == "dopri5" else TOL, what=f"{d.name} streamed poses")
+    # a drive streamed alone gives the same poses as in the lock-step batch
+    alone = tester.test_paths(model, drives[1:2])[0]
+    assert_close(torch.from_numpy(alone), torch.from_numpy(est[1]), tol=1e-5, what="lock-step vs alone")
