@@ -52,6 +52,10 @@ struct odevio_plan {
   int F = 0;
   // encoder
   float* conv_w[9] = {};
+  void* conv_ws[9] = {};   // conv2..conv6 weights as three bf16 planes (conv_split.hip), [Cout][K-tile][3][16]
+  int conv_math = 6;       // 6 / 3: split-operand bf16 MFMA with that many plane pairs; 0: fp32-input MFMA (ODEVIO_CONV_MATH)
+  DevBuf pack_tmp;
+  void* zero_page = nullptr;  // what the split kernel's LDS-DMA reads for taps outside the image
   float* conv_scale[9] = {};
   float* conv_shift[9] = {};
   int conv_h[10] = {}, conv_w_sp[10] = {};  // spatial size before conv i (index 0 = image)
@@ -146,6 +150,40 @@ static int bn_fold(const WeightTable& wt, const std::string& bn, int c, const st
   return 0;
 }
 
+// fp32 -> three bf16 pieces x = h + m + l (round to nearest even each time; the remainders are exact in fp32)
+static uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// [Cout][Cin][kh][kw] fp32 -> [Cout][K-tile][3 planes][16] bf16, K-tile = group * taps + tap (conv_split.hip)
+static void split_conv_weights(const std::vector<float>& w, int cout, int cin, int kk, std::vector<uint16_t>& out) {
+  const int groups = cin / 16;
+  out.assign((size_t)cout * groups * kk * 48, 0);
+  for (int n = 0; n < cout; ++n)
+    for (int c = 0; c < cin; ++c)
+      for (int q = 0; q < kk; ++q) {
+        const float x = w[((size_t)n * cin + c) * kk + q];
+        const uint16_t h = f32_to_bf16(x);
+        float r = x - bf16_to_f32(h);
+        const uint16_t m = f32_to_bf16(r);
+        r -= bf16_to_f32(m);
+        const uint16_t l = f32_to_bf16(r);
+        const size_t base = (((size_t)n * groups + c / 16) * kk + q) * 48 + (c % 16);
+        out[base] = h;
+        out[base + 16] = m;
+        out[base + 32] = l;
+      }
+}
+
 // [N][K] row-major -> per-member slices [member][j][col][ks][4] (integrator.hip, layer()).
 // The K axis is given as segments (each padded with zeros to a multiple of 256 = 64 lanes x 4 floats): lane l of
 // a wave multiplies inputs 256j + 4l .. 4l+3 of chunk j, so its weights for (chunk, column) are one float4.
@@ -176,7 +214,7 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (!p) return;
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->hT_scratch, &p->cde_ws})
+                    &p->hT_scratch, &p->cde_ws, &p->pack_tmp})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
@@ -251,7 +289,18 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   } while (0)
 
   std::vector<float> w, t, sc, sh, bias;
+  if (const char* cm = getenv("ODEVIO_CONV_MATH")) {  // diagnostic override; the default is the fp32-accurate split
+    if (!strcmp(cm, "f32")) p->conv_math = 0;
+    else if (!strcmp(cm, "bf16x3")) p->conv_math = 6;
+    else if (!strcmp(cm, "bf16x2")) p->conv_math = 3;
+    else {
+      odevio_plan_destroy(p);
+      return fail(ODEVIO_ERR_BAD_ARG, "ODEVIO_CONV_MATH must be f32, bf16x3 or bf16x2");
+    }
+  }
   // ---- image encoder
+  TRY(dev_alloc(p, &p->zero_page, 256));
+  HIPCHK(hipMemsetAsync(p->zero_page, 0, 256, st));
   p->conv_h[0] = cfg->img_h;
   p->conv_w_sp[0] = cfg->img_w;
   for (int i = 0; i < 9; ++i) {
@@ -271,6 +320,13 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
           for (int q = 0; q < kk; ++q) t[((size_t)n * kk + q) * cs.cin + c] = w[((size_t)n * cs.cin + c) * kk + q];
     }
     TRY(upload(p, &p->conv_w[i], t, st));
+    if (i > 0) {
+      std::vector<uint16_t> ws;
+      split_conv_weights(w, cs.cout, cs.cin, cs.k * cs.k, ws);
+      TRY(dev_alloc(p, &p->conv_ws[i], ws.size() * sizeof(uint16_t)));
+      HIPCHK(hipMemcpyAsync(p->conv_ws[i], ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
     TRY(bn_fold(wt, pre + ".1", cs.cout, nullptr, sc, sh));
     TRY(upload(p, &p->conv_scale[i], sc, st));
     TRY(upload(p, &p->conv_shift[i], sh, st));
@@ -465,19 +521,63 @@ static int run_gemm(odevio_plan* p, const float* in, int M, int K, const float* 
   return 0;
 }
 
-static int conv_block(odevio_plan* p, int i, const float* in, int B, int S, float* out, hipStream_t st) {
+// Same cost model for the split-operand kernel: K-tiles are 16 channels, ~0.8 us per step of a CU running two
+// workgroups (24 bf16 MFMAs per wave and step).
+static int pick_splitk_split(int M, int N, int nk) {
+  const double tiles = (double)((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles >= 2048 || nk < 32) return 1;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
+    if (s > 1 && nk / s < 24) break;
+    const double rounds = std::ceil(tiles * s / 512.0);
+    const double steps = std::ceil((double)nk / s) + 8.0;
+    double cost = rounds * steps * 0.8;
+    if (s > 1) cost += (s + 1.0) * M * N * 4.0 / 4.0e6 + 8.0;
+    if (cost < best_cost * 0.97) {
+      best_cost = cost;
+      best = s;
+    }
+  }
+  return best;
+}
+
+// One encoder block.  Activations between blocks live in the P3 split layout when the split-operand kernel is in use
+// (in_split / out_split); fp32 NHWC otherwise.
+static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void* out, bool in_split, bool out_split,
+                      hipStream_t st) {
   const int P = B * (S - 1);
   const ConvSpec& cs = kConvs[i];
   if (i == 0) {
     Conv1Args a{};
-    a.img = in; a.wt = p->conv_w[0]; a.scale = p->conv_scale[0]; a.shift = p->conv_shift[0]; a.out = out;
+    a.img = (const float*)in; a.wt = p->conv_w[0]; a.scale = p->conv_scale[0]; a.shift = p->conv_shift[0]; a.out = out;
+    a.out_split = out_split;
     a.B = B; a.S = S; a.H = p->conv_h[0]; a.W = p->conv_w_sp[0]; a.Ho = p->conv_h[1]; a.Wo = p->conv_w_sp[1];
     a.tiles_y = (a.Ho + 7) / 8; a.tiles_x = (a.Wo + 31) / 32; a.n_tiles = P * a.tiles_y * a.tiles_x; a.slope = 0.1f;
     launch_conv1(a, p->n_cu, st);
     return 0;
   }
+  if (in_split) {
+    ConvSplitArgs a{};
+    a.in = in; a.w = p->conv_ws[i]; a.zeros = p->zero_page; a.scale = p->conv_scale[i]; a.shift = p->conv_shift[i]; a.out = out;
+    a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
+    a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
+    a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.terms = p->conv_math;
+    const int nk = cs.k * cs.k * cs.cin / 16;
+    a.splitk = pick_splitk_split(a.M, a.Cout, nk);
+    a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
+    a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
+    if (a.splitk > 1) {
+      int rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout);
+      if (rc) return rc;
+      a.partial = p->partial.p;
+    }
+    launch_conv_split(a, st);
+    return 0;
+  }
+  if (out_split) return fail(ODEVIO_ERR_BAD_ARG, "conv_block: fp32-input blocks write fp32");
   ConvArgs a{};
-  a.in = in; a.w = p->conv_w[i]; a.scale = p->conv_scale[i]; a.shift = p->conv_shift[i]; a.out = out;
+  a.in = (const float*)in; a.w = p->conv_w[i]; a.scale = p->conv_scale[i]; a.shift = p->conv_shift[i]; a.out = (float*)out;
   a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
   a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
   a.M = P * a.Ho * a.Wo; a.ld_out = cs.cout; a.act = EPI_LEAKY; a.slope = 0.1f;
@@ -494,23 +594,31 @@ static int conv_block(odevio_plan* p, int i, const float* in, int B, int S, floa
   return 0;
 }
 
-static int image_encoder(odevio_plan* p, const float* img, int B, int S, float* fv, int ld_fv, hipStream_t st) {
-  const int P = B * (S - 1);
+// Ping-pong activation buffers of the encoder, in floats; the P3 split layout needs 6 bytes per element.
+static int ensure_act(odevio_plan* p, int P) {
   size_t nA = 0, nB = 0;
   for (int i = 0; i < 9; ++i) {
-    const size_t n = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * kConvs[i].cout;
-    if (i == 0 || i == 2 || i == 4 || i == 6 || i == 8) nA = std::max(nA, n); else nB = std::max(nB, n);
+    size_t n = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * kConvs[i].cout;
+    if (p->conv_math != 0 && i < 8) n += n / 2;
+    if (i % 2 == 0) nA = std::max(nA, n); else nB = std::max(nB, n);
   }
   int rc;
   if ((rc = ensure(p->actA, nA))) return rc;
-  if ((rc = ensure(p->actB, nB))) return rc;
+  return ensure(p->actB, nB);
+}
+
+static int image_encoder(odevio_plan* p, const float* img, int B, int S, float* fv, int ld_fv, hipStream_t st) {
+  const int P = B * (S - 1);
+  int rc;
+  if ((rc = ensure_act(p, P))) return rc;
+  const bool split = p->conv_math != 0;  // conv1 .. conv5_1 hand their output over in the P3 split layout
   stage_mark(p, 0, st);
-  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, st))) return rc;
+  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, false, split, st))) return rc;
   stage_mark(p, 1, st);
   float* cur = p->actA.p;
   for (int i = 1; i < 9; ++i) {
     float* nxt = (cur == p->actA.p) ? p->actB.p : p->actA.p;
-    if ((rc = conv_block(p, i, cur, B, S, nxt, st))) return rc;
+    if ((rc = conv_block(p, i, cur, B, S, nxt, split, split && i < 8, st))) return rc;
     cur = nxt;
   }
   stage_mark(p, 2, st);
@@ -728,13 +836,8 @@ static int regress(odevio_plan* p, const float* seq, int M, float* poses, hipStr
 extern "C" int odevio_reserve(odevio_plan* p, int32_t B, int32_t S, void* stream) {
   ARGCHK(p && B > 0 && S > 1, "odevio_reserve: bad argument");
   const int P = B * (S - 1);
-  size_t nA = 0, nB = 0;
-  for (int i = 0; i < 9; ++i) {
-    const size_t n = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * kConvs[i].cout;
-    if (i % 2 == 0) nA = std::max(nA, n); else nB = std::max(nB, n);
-  }
   int rc;
-  if ((rc = ensure(p->actA, nA)) || (rc = ensure(p->actB, nB)) || (rc = ensure(p->imu_act, (size_t)P * 2816)) ||
+  if ((rc = ensure_act(p, P)) || (rc = ensure(p->imu_act, (size_t)P * 2816)) ||
       (rc = ensure(p->fcat, (size_t)P * p->F)) || (rc = ensure(p->fused, (size_t)P * p->F)) ||
       (rc = ensure(p->out_seq, (size_t)P * p->F)) || (rc = ensure(p->reg_hid, (size_t)P * 128)) ||
       (rc = ensure(p->partial, (size_t)64 * P * std::max(p->cfg.v_f_len, 128))))
@@ -796,7 +899,16 @@ extern "C" int odevio_image_encoder_fwd(odevio_plan* p, const float* img, int32_
 extern "C" int odevio_conv_block_fwd(odevio_plan* p, int32_t layer, const float* in, int32_t B, int32_t S, float* out,
                                      void* stream) {
   ARGCHK(p && in && out && layer >= 0 && layer < 9 && B > 0 && S > 1, "odevio_conv_block_fwd: bad argument");
-  return conv_block(p, layer, in, B, S, out, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (layer == 0 || p->conv_math == 0) return conv_block(p, layer, in, B, S, out, false, false, st);
+  // fp32 NHWC at this boundary: split the input into the kernel's three-plane layout first (the encoder itself never
+  // converts - each block's epilogue writes the next block's layout)
+  const size_t pixels = (size_t)B * (S - 1) * p->conv_h[layer] * p->conv_w_sp[layer];
+  const int C = kConvs[layer].cin;
+  int rc = ensure(p->pack_tmp, pixels * C * 3 / 2);
+  if (rc) return rc;
+  launch_split_pack(in, p->pack_tmp.p, pixels, C, st);
+  return conv_block(p, layer, p->pack_tmp.p, B, S, out, true, false, st);
 }
 
 extern "C" int odevio_imu_encoder_fwd(odevio_plan* p, const float* imu, int32_t B, int32_t T, float* fi,

@@ -421,7 +421,8 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
       for (int mt = 0; mt < 2; ++mt) {
         const int oy = ty * C1_TH + 2 * wave + mt;
         if (oy >= a.Ho || ox >= a.Wo) continue;
-        float* orow = a.out + (((size_t)pair * a.Ho + oy) * a.Wo + ox) * 64;
+        const size_t opix = ((size_t)pair * a.Ho + oy) * a.Wo + ox;
+        float* orow = reinterpret_cast<float*>(a.out) + opix * 64;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -435,7 +436,8 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
               const float x = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
               v[e] = x > 0.f ? x : x * a.slope;
             }
-            *reinterpret_cast<f32x4*>(orow + n) = v;
+            if (a.out_split) store_split4(reinterpret_cast<unsigned char*>(a.out), opix, n, 64, v);
+            else *reinterpret_cast<f32x4*>(orow + n) = v;
           }
         }
       }
