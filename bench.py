@@ -34,8 +34,13 @@ from odevio_amd import default_opt, synth, weights  # noqa: E402
 
 METRIC = "ODE integrator steps/s (hidden=512, RK4) + frames/s on KITTI seq-len 11"
 B, S, H, W = 16, 11, 256, 512
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (fp32-input MFMA)
+F16_MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA
 HBM_PEAK_GBS = 8000.0
+# conv2..conv6 multiply fp32 operands held as two fp16 pieces with 3 fp16 MFMAs per fp32 product:
+# executed MFMA flops = 3 x algorithmic flops.  ODEVIO_CONV_MATH=f32 selects the fp32-input MFMA kernel instead.
+CONV_MATH = os.environ.get("ODEVIO_CONV_MATH", "f16x2")
+MFMA_PER_PRODUCT = {"f16x2": 3, "f32": 1}[CONV_MATH]
 
 
 def conv_flops_per_pair():
@@ -55,6 +60,23 @@ def ode_bytes_per_rk4_step(opt, rows):
     dims = [F] + [opt.ode_hidden_dim] * opt.ode_fn_num_layers + [F]
     params = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
     return 4 * params * 4 + 2 * rows * F * 4
+
+
+def conv_roofline(conv_tflops):
+    """Roofline of the dominant kernel (conv2..conv6).  `achieved` is ALGORITHMIC fp32 TFLOP/s; the peak it is priced
+    against is the MFMA peak of the instructions the kernel executes divided by the MFMAs it needs per fp32 product."""
+    if CONV_MATH == "f32":
+        peak, kern, key = FP32_MFMA_PEAK_TFLOPS, "conv_igemm_kernel (conv2..conv6, fp32-input MFMA)", "conv_igemm_kernel [dispatches > 0.4 ms]"
+    else:
+        peak, kern, key = F16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT, "conv_f16x2_kernel (conv2..conv6)", "conv_f16x2_kernel"
+    return {"kernel": kern, "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(conv_tflops / peak, 4), "traffic": pmc_traffic(key),
+            "executed_mfma_tflops": round(conv_tflops * MFMA_PER_PRODUCT, 1),
+            "executed_mfma_peak": FP32_MFMA_PEAK_TFLOPS if CONV_MATH == "f32" else F16_MFMA_PEAK_TFLOPS,
+            "note": f"fp32 operands as two fp16 pieces (22-bit significands), {MFMA_PER_PRODUCT} fp16 MFMAs per fp32 product, fp32 accumulate; "
+                    f"peak = dense fp16 MFMA peak / {MFMA_PER_PRODUCT}; the fp32-input MFMA peak is 157.3; "
+                    "traffic = HBM bytes per forward of these launches from profiles/r01_pmc_traffic.json" if CONV_MATH != "f32" else
+                    "fp32-input MFMA; traffic = HBM bytes per forward from profiles/r01_pmc_traffic.json"}
 
 
 def pmc_traffic(kernel_key):
@@ -188,16 +210,14 @@ def main():
             "metric": METRIC, "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 in, fp32 out, fp32 accumulate everywhere; conv2..conv6 products via " + CONV_MATH + (" operand split: operands to 2^-22, products exact, see DESIGN.md section 4" if CONV_MATH != "f32" else " MFMA"),
             "config": {"workload": f"DeepVIO.forward: {B} sequences x {S} frames 256x512 per GPU, ODEFunc 768-512-512-512-768, "
                                    f"RK4 (3/8) 1 step/interval, 2-layer tanh RNN, fp32 (BASELINE configs[1])",
                        "sequences_per_gpu": B, "seq_len": S, "ode_solver": "rk4", "sharding": f"sequences x{world}"},
             "integrator": {"steps_per_s": round(n_rk4 / integ_s, 1), "rows": rows, "unit": "RK4 steps/s of the [32,768] state, inside the ODE-RNN loop (RNN cell included)",
                            "ms_per_forward": round(stage_ms["integrator"], 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"kernel": "conv_igemm_kernel (conv2..conv6)", "bound": "mfma", "achieved": round(conv_tflops, 2),
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("conv_igemm_kernel [dispatches > 0.4 ms]"),
-                         "traffic_note": "HBM bytes per forward (8 conv launches) from profiles/r01_pmc_traffic.json; algorithmic activations in+out = 4.9e9"},
+            "roofline": conv_roofline(conv_tflops),
             "roofline_integrator": {"kernel": "integrator_kernel", "bound": "hbm",
                                     "achieved": round(integ_bytes / integ_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(integ_bytes / integ_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("integrator_kernel<4>"),

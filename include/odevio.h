@@ -40,7 +40,8 @@ enum odevio_status {
   ODEVIO_ERR_HIP = -4,          /* a HIP runtime call failed                                  */
   ODEVIO_ERR_NO_DEVICE = -5,
   ODEVIO_ERR_TIMEOUT = -6,      /* a bounded in-kernel wait gave up (reported by odevio_check)*/
-  ODEVIO_ERR_MAX_STEPS = -7     /* adaptive solver exceeded max_steps (reported by check)     */
+  ODEVIO_ERR_MAX_STEPS = -7,    /* adaptive solver exceeded max_steps (reported by check)     */
+  ODEVIO_ERR_RANGE = -8         /* an encoder activation left the fp16x2 range (reported by check) */
 };
 
 /* reference src/models/ODEFunc.py:23-36 */

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODEVIO_LIB", os.path.join(_HERE, "libodevio.so"))  # ODEVIO_LIB: diagnostic builds
 
 ODEVIO_OK = 0
-ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_MISSING_WEIGHT, ERR_HIP, ERR_NO_DEVICE, ERR_TIMEOUT, ERR_MAX_STEPS = range(-1, -8, -1)
+ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_MISSING_WEIGHT, ERR_HIP, ERR_NO_DEVICE, ERR_TIMEOUT, ERR_MAX_STEPS, ERR_RANGE = range(-1, -9, -1)
 
 ACTIVATIONS = {"tanh": 0, "relu": 1, "leaky_relu": 2, "softplus": 3}
 SOLVERS = {"dopri5": 0, "heun": 1, "tsit5": 2, "euler": 3, "rk4": 4, "runge_kutta": 4, "rk4_classic": 5}

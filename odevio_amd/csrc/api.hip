@@ -52,8 +52,9 @@ struct odevio_plan {
   int F = 0;
   // encoder
   float* conv_w[9] = {};
-  void* conv_ws[9] = {};   // conv2..conv6 weights as three bf16 planes (conv_split.hip), [Cout][K-tile][3][16]
-  int conv_math = 6;       // 6 / 3: split-operand bf16 MFMA with that many plane pairs; 0: fp32-input MFMA (ODEVIO_CONV_MATH)
+  void* conv_ws[9] = {};   // conv2..conv6 weights as two fp16 pieces (conv_f16x2.hip), [Cout][K-tile][2][32], pre-scaled
+  float* conv_scale_h[9] = {};  // BatchNorm scale with the weights' power-of-two pre-scale folded back in
+  int conv_math = 1;       // 1: fp16x2 operand split on the fp16 MFMA (default); 0: fp32-input MFMA (ODEVIO_CONV_MATH=f32)
   DevBuf pack_tmp;
   void* zero_page = nullptr;  // what the split kernel's LDS-DMA reads for taps outside the image
   float* conv_scale[9] = {};
@@ -150,38 +151,33 @@ static int bn_fold(const WeightTable& wt, const std::string& bn, int c, const st
   return 0;
 }
 
-// fp32 -> three bf16 pieces x = h + m + l (round to nearest even each time; the remainders are exact in fp32)
-static uint16_t f32_to_bf16(float f) {
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-static float bf16_to_f32(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-// [Cout][Cin][kh][kw] fp32 -> [Cout][K-tile][3 planes][16] bf16, K-tile = group * taps + tap (conv_split.hip)
-static void split_conv_weights(const std::vector<float>& w, int cout, int cin, int kk, std::vector<uint16_t>& out) {
-  const int groups = cin / 16;
-  out.assign((size_t)cout * groups * kk * 48, 0);
+// [Cout][Cin][kh][kw] fp32 -> [Cout][K-tile][2 pieces][32] fp16, K-tile = group * taps + tap (conv_f16x2.hip).
+// x * prescale = h + l, h = fp16(.), l = fp16(. - h) (round to nearest even, subnormals kept).  `prescale` is a power of
+// two that lifts the layer's largest weight to [2^13, 2^14): the low pieces of all but vanishing weights are then normal
+// fp16 numbers, and 1/prescale goes into the BatchNorm scale exactly.
+static float split_conv_weights(const std::vector<float>& w, int cout, int cin, int kk, std::vector<uint16_t>& out) {
+  float wmax = 0.f;
+  for (float x : w) wmax = std::max(wmax, std::fabs(x));
+  int e = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) {
+    (void)std::frexp(wmax, &e);   // wmax = f * 2^e, f in [0.5, 1)
+    e = 14 - e;                   // wmax * 2^e in [2^13, 2^14)
+  }
+  e = std::max(-40, std::min(40, e));
+  const float prescale = std::ldexp(1.0f, e);
+  const int groups = cin / 32;
+  out.assign((size_t)cout * groups * kk * 64, 0);
   for (int n = 0; n < cout; ++n)
     for (int c = 0; c < cin; ++c)
       for (int q = 0; q < kk; ++q) {
-        const float x = w[((size_t)n * cin + c) * kk + q];
-        const uint16_t h = f32_to_bf16(x);
-        float r = x - bf16_to_f32(h);
-        const uint16_t m = f32_to_bf16(r);
-        r -= bf16_to_f32(m);
-        const uint16_t l = f32_to_bf16(r);
-        const size_t base = (((size_t)n * groups + c / 16) * kk + q) * 48 + (c % 16);
-        out[base] = h;
-        out[base + 16] = m;
-        out[base + 32] = l;
+        const float x = w[((size_t)n * cin + c) * kk + q] * prescale;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const size_t base = (((size_t)n * groups + c / 32) * kk + q) * 64 + (c % 32);
+        memcpy(&out[base], &h, 2);
+        memcpy(&out[base + 32], &l, 2);
       }
+  return prescale;
 }
 
 // [N][K] row-major -> per-member slices [member][j][col][ks][4] (integrator.hip, layer()).
@@ -291,11 +287,10 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   std::vector<float> w, t, sc, sh, bias;
   if (const char* cm = getenv("ODEVIO_CONV_MATH")) {  // diagnostic override; the default is the fp32-accurate split
     if (!strcmp(cm, "f32")) p->conv_math = 0;
-    else if (!strcmp(cm, "bf16x3")) p->conv_math = 6;
-    else if (!strcmp(cm, "bf16x2")) p->conv_math = 3;
+    else if (!strcmp(cm, "f16x2")) p->conv_math = 1;
     else {
       odevio_plan_destroy(p);
-      return fail(ODEVIO_ERR_BAD_ARG, "ODEVIO_CONV_MATH must be f32, bf16x3 or bf16x2");
+      return fail(ODEVIO_ERR_BAD_ARG, "ODEVIO_CONV_MATH must be f16x2 or f32");
     }
   }
   // ---- image encoder
@@ -320,14 +315,20 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
           for (int q = 0; q < kk; ++q) t[((size_t)n * kk + q) * cs.cin + c] = w[((size_t)n * cs.cin + c) * kk + q];
     }
     TRY(upload(p, &p->conv_w[i], t, st));
+    float prescale = 1.f;
     if (i > 0) {
       std::vector<uint16_t> ws;
-      split_conv_weights(w, cs.cout, cs.cin, cs.k * cs.k, ws);
+      prescale = split_conv_weights(w, cs.cout, cs.cin, cs.k * cs.k, ws);
       TRY(dev_alloc(p, &p->conv_ws[i], ws.size() * sizeof(uint16_t)));
       HIPCHK(hipMemcpyAsync(p->conv_ws[i], ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
     }
     TRY(bn_fold(wt, pre + ".1", cs.cout, nullptr, sc, sh));
+    if (i > 0) {
+      std::vector<float> sch(sc);
+      for (float& v : sch) v /= prescale;   // exact: prescale is a power of two
+      TRY(upload(p, &p->conv_scale_h[i], sch, st));
+    }
     TRY(upload(p, &p->conv_scale[i], sc, st));
     TRY(upload(p, &p->conv_shift[i], sh, st));
   }
@@ -521,18 +522,17 @@ static int run_gemm(odevio_plan* p, const float* in, int M, int K, const float* 
   return 0;
 }
 
-// Same cost model for the split-operand kernel: K-tiles are 16 channels, ~0.8 us per step of a CU running two
-// workgroups (24 bf16 MFMAs per wave and step).
-static int pick_splitk_split(int M, int N, int nk) {
-  const double tiles = (double)((M + 127) / 128) * ((N + 127) / 128);
-  if (tiles >= 2048 || nk < 32) return 1;
+// Same cost model for the fp16x2 kernel: 256 x 128 tiles, one workgroup per CU, K-tiles of 32 channels at ~0.45 us.
+static int pick_splitk_h(int M, int N, int nk) {
+  const double tiles = (double)((M + 255) / 256) * ((N + 127) / 128);
+  if (tiles >= 1024 || nk < 24) return 1;
   int best = 1;
   double best_cost = 1e30;
-  for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
-    if (s > 1 && nk / s < 24) break;
-    const double rounds = std::ceil(tiles * s / 512.0);
-    const double steps = std::ceil((double)nk / s) + 8.0;
-    double cost = rounds * steps * 0.8;
+  for (int s : {1, 2, 3, 4, 6, 8, 12}) {
+    if (s > 1 && nk / s < 12) break;
+    const double rounds = std::ceil(tiles * s / 256.0);
+    const double steps = std::ceil((double)nk / s) + 6.0;
+    double cost = rounds * steps * 0.45;
     if (s > 1) cost += (s + 1.0) * M * N * 4.0 / 4.0e6 + 8.0;
     if (cost < best_cost * 0.97) {
       best_cost = cost;
@@ -542,7 +542,7 @@ static int pick_splitk_split(int M, int N, int nk) {
   return best;
 }
 
-// One encoder block.  Activations between blocks live in the P3 split layout when the split-operand kernel is in use
+// One encoder block.  Activations between blocks live in the P2 split layout when the fp16x2 kernel is in use
 // (in_split / out_split); fp32 NHWC otherwise.
 static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void* out, bool in_split, bool out_split,
                       hipStream_t st) {
@@ -551,7 +551,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
   if (i == 0) {
     Conv1Args a{};
     a.img = (const float*)in; a.wt = p->conv_w[0]; a.scale = p->conv_scale[0]; a.shift = p->conv_shift[0]; a.out = out;
-    a.out_split = out_split;
+    a.out_split = out_split; a.status = p->status;
     a.B = B; a.S = S; a.H = p->conv_h[0]; a.W = p->conv_w_sp[0]; a.Ho = p->conv_h[1]; a.Wo = p->conv_w_sp[1];
     a.tiles_y = (a.Ho + 7) / 8; a.tiles_x = (a.Wo + 31) / 32; a.n_tiles = P * a.tiles_y * a.tiles_x; a.slope = 0.1f;
     launch_conv1(a, p->n_cu, st);
@@ -559,12 +559,12 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
   }
   if (in_split) {
     ConvSplitArgs a{};
-    a.in = in; a.w = p->conv_ws[i]; a.zeros = p->zero_page; a.scale = p->conv_scale[i]; a.shift = p->conv_shift[i]; a.out = out;
+    a.in = in; a.w = p->conv_ws[i]; a.zeros = p->zero_page; a.scale = p->conv_scale_h[i]; a.shift = p->conv_shift[i]; a.out = out; a.status = p->status;
     a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
     a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
-    a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.terms = p->conv_math;
-    const int nk = cs.k * cs.k * cs.cin / 16;
-    a.splitk = pick_splitk_split(a.M, a.Cout, nk);
+    a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split;
+    const int nk = cs.k * cs.k * cs.cin / 32;
+    a.splitk = pick_splitk_h(a.M, a.Cout, nk);
     a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
     a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
     if (a.splitk > 1) {
@@ -572,7 +572,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
       if (rc) return rc;
       a.partial = p->partial.p;
     }
-    launch_conv_split(a, st);
+    HIPCHK(launch_conv_f16x2(a, st));
     return 0;
   }
   if (out_split) return fail(ODEVIO_ERR_BAD_ARG, "conv_block: fp32-input blocks write fp32");
@@ -594,12 +594,11 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
   return 0;
 }
 
-// Ping-pong activation buffers of the encoder, in floats; the P3 split layout needs 6 bytes per element.
+// Ping-pong activation buffers of the encoder, in floats (the P2 split layout is 4 bytes per element too).
 static int ensure_act(odevio_plan* p, int P) {
   size_t nA = 0, nB = 0;
   for (int i = 0; i < 9; ++i) {
     size_t n = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * kConvs[i].cout;
-    if (p->conv_math != 0 && i < 8) n += n / 2;
     if (i % 2 == 0) nA = std::max(nA, n); else nB = std::max(nB, n);
   }
   int rc;
@@ -611,7 +610,7 @@ static int image_encoder(odevio_plan* p, const float* img, int B, int S, float* 
   const int P = B * (S - 1);
   int rc;
   if ((rc = ensure_act(p, P))) return rc;
-  const bool split = p->conv_math != 0;  // conv1 .. conv5_1 hand their output over in the P3 split layout
+  const bool split = p->conv_math != 0;  // conv1 .. conv5_1 hand their output over in the P2 split layout
   stage_mark(p, 0, st);
   if ((rc = conv_block(p, 0, img, B, S, p->actA.p, false, split, st))) return rc;
   stage_mark(p, 1, st);
@@ -878,9 +877,16 @@ extern "C" int odevio_debug_stamps(odevio_plan* p, uint64_t* out8, void* stream)
 extern "C" int odevio_check(odevio_plan* p, void* stream) {
   ARGCHK(p, "odevio_check: null plan");
   hipStream_t st = (hipStream_t)stream;
-  int h = 0;
-  HIPCHK(hipMemcpyAsync(&h, p->status, sizeof(int), hipMemcpyDeviceToHost, st));
+  int hw[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(hw, p->status, sizeof(hw), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (hw[ODEVIO_STATUS_RANGE] != 0) {
+    HIPCHK(hipMemsetAsync(p->status + ODEVIO_STATUS_RANGE, 0, sizeof(int), st));
+    HIPCHK(hipStreamSynchronize(st));
+    return fail(ODEVIO_ERR_RANGE, "image encoder: an activation left the fp16x2 range (|x| > 65504 or not finite); "
+                                  "set ODEVIO_CONV_MATH=f32 for the fp32-input MFMA path");
+  }
+  const int h = hw[0];
   if (h != 0) {
     HIPCHK(hipMemsetAsync(p->status, 0, sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
@@ -901,13 +907,13 @@ extern "C" int odevio_conv_block_fwd(odevio_plan* p, int32_t layer, const float*
   ARGCHK(p && in && out && layer >= 0 && layer < 9 && B > 0 && S > 1, "odevio_conv_block_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (layer == 0 || p->conv_math == 0) return conv_block(p, layer, in, B, S, out, false, false, st);
-  // fp32 NHWC at this boundary: split the input into the kernel's three-plane layout first (the encoder itself never
+  // fp32 NHWC at this boundary: split the input into the kernel's two-piece layout first (the encoder itself never
   // converts - each block's epilogue writes the next block's layout)
   const size_t pixels = (size_t)B * (S - 1) * p->conv_h[layer] * p->conv_w_sp[layer];
   const int C = kConvs[layer].cin;
-  int rc = ensure(p->pack_tmp, pixels * C * 3 / 2);
+  int rc = ensure(p->pack_tmp, pixels * C);
   if (rc) return rc;
-  launch_split_pack(in, p->pack_tmp.p, pixels, C, st);
+  launch_pair_pack(in, p->pack_tmp.p, pixels, C, p->status, st);
   return conv_block(p, layer, p->pack_tmp.p, B, S, out, true, false, st);
 }
 

@@ -28,23 +28,24 @@ struct ConvArgs {
   int xcd_map;          // set by the launcher: XCD-aware tile order (>= 16 M tiles)
 };
 
-// Same convolution with fp32 operands carried as three bf16 planes (conv_split.hip).
-//   in  : P3 layout [pixel][Cin/16][3][16] bf16;  w : [Cout][K-tile][3][16] bf16, K-tile = (channel group, tap), tap minor
-//   out : P3 (out_split = 1) or fp32 [M][Cout];  Cin % 16 == 0, Cout % 16 == 0
+// Same convolution with fp32 operands carried as two fp16 pieces (conv_f16x2.hip).
+//   in  : P2 layout [pixel][Cin/32][2][32] fp16;  w : [Cout][K-tile][2][32] fp16, K-tile = (channel group, tap), tap minor
+//   out : P2 (out_split = 1) or fp32 [M][Cout];  Cin % 32 == 0, Cout % 32 == 0
+#define ODEVIO_STATUS_RANGE 2   // word of the plan's status buffer raised when an activation leaves the fp16 range
 struct ConvSplitArgs {
   const void* in;
   const void* w;
   const void* zeros;    // >= 128 zero bytes: what the LDS-DMA reads for taps outside the image
-  const float* scale;   // [Cout]
+  const float* scale;   // [Cout] (BatchNorm scale with the weights' power-of-two pre-scale folded in)
   const float* shift;   // [Cout]
   void* out;
   float* partial;       // split-K slabs [splitk][M][Cout] fp32 when splitk > 1
+  int* status;
   int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int M;
   float slope;          // LeakyReLU slope (the only epilogue the encoder needs)
   int out_split;
   int splitk, ktiles_per_split;
-  int terms;            // 6: fp32-accurate product (default); 3: hh + hm + mh only (16-bit significands)
   int xcd_map;
 };
 
@@ -54,8 +55,9 @@ struct Conv1Args {
   const float* wt;      // [294][64]  (k = c*49 + kh*7 + kw, c in 0..5)
   const float* scale;   // [64]
   const float* shift;   // [64]
-  void* out;            // NHWC [P][Ho][Wo][64] fp32, or the same pixels in P3 layout (out_split)
+  void* out;            // NHWC [P][Ho][Wo][64] fp32, or the same pixels in P2 layout (out_split)
   int out_split;
+  int* status;
   int B, S, H, W, Ho, Wo;
   int tiles_y, tiles_x, n_tiles;  // per-pair tile grid and total tile count
   float slope;
@@ -76,30 +78,30 @@ struct ImuArgs {
 void launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 void launch_conv1(const Conv1Args& a, int n_cu, hipStream_t st);
 void launch_imu_convs(const ImuArgs& a, hipStream_t st);
-void launch_conv_split(const ConvSplitArgs& a, hipStream_t st);
-void launch_split_pack(const float* in, void* out, size_t pixels, int C, hipStream_t st);     // fp32 [pixel][C] -> P3
-void launch_split_unpack(const void* in, float* out, size_t pixels, int C, hipStream_t st);   // P3 -> fp32 [pixel][C]
+hipError_t launch_conv_f16x2(const ConvSplitArgs& a, hipStream_t st);
+void launch_pair_pack(const float* in, void* out, size_t pixels, int C, int* status, hipStream_t st);   // fp32 [pixel][C] -> P2
+void launch_pair_unpack(const void* in, float* out, size_t pixels, int C, hipStream_t st);              // P2 -> fp32 [pixel][C]
 // pose.hip: relative 6-DoF poses -> global 4x4 matrices, one workgroup per drive (all pointers on the device)
 hipError_t launch_path_accu(const void* poses, int is_f64, const int64_t* offsets_dev, int n_drives, const double* carry,
                             double* out, hipStream_t stream);
 
-// x = h + m + l with bf16 pieces (each the round-to-nearest bf16 of what is left; the subtractions are exact), written
-// to the three planes of a P3 tensor [pixel][C/16][3][16] for 4 consecutive channels n..n+3 (n % 4 == 0).
-__device__ __forceinline__ void store_split4(unsigned char* base, size_t pixel, int n, int C, f32x4 v) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  bf16x4 h, m, l;
+// x = h + l with fp16 pieces (h = fp16(x), l = fp16(x - h); the subtraction is exact), written to the two halves of a
+// P2 block [pixel][C/32][2][32] for 4 consecutive channels n..n+3 (n % 4 == 0).  Returns true when a value is outside
+// the fp16 range (the caller raises the plan's status word; such an activation cannot be represented).
+__device__ __forceinline__ bool store_pair4(unsigned char* base, size_t pixel, int n, int C, f32x4 v) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 h, l;
+  bool bad = false;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    h[e] = (__bf16)v[e];
-    float r = v[e] - (float)h[e];
-    m[e] = (__bf16)r;
-    r -= (float)m[e];
-    l[e] = (__bf16)r;
+    bad |= !(fabsf(v[e]) <= 65504.f);
+    h[e] = (_Float16)v[e];
+    l[e] = (_Float16)(v[e] - (float)h[e]);
   }
-  unsigned char* p = base + (pixel * (size_t)(C >> 4) + (size_t)(n >> 4)) * 96 + (n & 15) * 2;
-  *reinterpret_cast<bf16x4*>(p) = h;
-  *reinterpret_cast<bf16x4*>(p + 32) = m;
-  *reinterpret_cast<bf16x4*>(p + 64) = l;
+  unsigned char* p = base + (pixel * (size_t)(C >> 5) + (size_t)(n >> 5)) * 128 + (n & 31) * 2;
+  *reinterpret_cast<f16x4*>(p) = h;
+  *reinterpret_cast<f16x4*>(p + 64) = l;
+  return bad;
 }
 
 __device__ __forceinline__ float apply_epi(float v, int act, float slope) {

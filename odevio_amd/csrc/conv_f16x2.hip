@@ -1,0 +1,341 @@
+// Implicit-GEMM convolution on the fp16 MFMA with fp32 operands carried as TWO fp16 pieces ("f16x2"), gfx950.
+//
+// Replaces the same reference blocks as conv_igemm.hip (Conv2d + BatchNorm2d(eval) + LeakyReLU(0.1) of the
+// ImageEncoder, src/models/Encoder.py:8-22,116-122) for conv2..conv6 - the 2.3 TFLOP that dominate DeepVIO.forward.
+//
+// Why: the fp32-input MFMA runs at the vector rate, 1/16 of the 16-bit MFMA.  Write an fp32 number as x = h + l with
+// h = fp16(x), l = fp16(x - h): 11 + 11 significand bits, i.e. x to 2^-22 (fp32 itself: 2^-24; the 3xTF32 scheme of
+// other BLAS libraries: 2^-21).  fp16 x fp16 products are exact in the MFMA's fp32 accumulator, so
+//     x*w = h_x h_w + h_x l_w + l_x h_w + [l_x l_w]          (bracket < 2^-22 of the product, dropped)
+// is three MFMAs per product, accumulated in fp32 like the fp32 MFMA does: 3/16 of its cost.  The MI355X MFMA honours
+// fp16 subnormals (tools/probes/f16_denorm_mfma.hip), so l keeps an absolute resolution of 2^-24 for small x.
+// Range: |activation| must stay below 65504 (BatchNorm'd, LeakyReLU'd features are O(1)); the epilogues raise the
+// plan's status word otherwise and odevio_check reports it.  Weights are pre-scaled by a power of two per layer
+// (folded back into the BatchNorm scale) so that their low pieces are normal numbers.
+//
+// Layout ("P2"): activations [pixel][C/32][2 pieces][32 channels] fp16 - one 128-byte cache line per pixel and
+// 32-channel group, 4 B per element like fp32.  Producers (conv1, this kernel, the split-K combine) split their fp32
+// result once in the epilogue.  Weights: [Cout][K-tile][2][32] with K-tile = (channel group, tap), tap minor.
+//
+// Tiling: 256 pixels x 128 output channels x 32 input channels per 512-thread workgroup (8 waves as 4 x 2, 64x64
+// each: 2x2 MFMA 32x32x16 tiles x 2 k-steps x 3 piece pairs = 24 MFMAs per K-tile), one workgroup per CU.
+// Staging is LDS-DMA (global_load_lds_dwordx4, no staging registers, no ds_write pass): one wave instruction moves
+// 8 rows x 128 B - eight whole cache lines - into 1 KB of LDS.  The LDS image of a row is its 128-byte line with the
+// eight 16-byte pieces XOR-permuted by (row >> 1) & 7 (applied on the SOURCE address, the DMA writes lane-linearly),
+// which makes the ds_read_b128 fragment reads conflict-free.  Three stages (48 KB each); taps outside the image read
+// a zero page.  Barriers are raw s_barrier with counted vmcnt (a __syncthreads() would drain the DMAs).
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define HBM_ 256            // pixels per tile
+#define HBN_ 128            // output channels per tile
+#define HROW 128            // bytes of one (row, K-tile) block: 2 pieces x 32 channels x 2 B
+#define HA_BYTES (HBM_ * HROW)
+#define HSTAGE ((HBM_ + HBN_) * HROW)   // 48 KB
+#define HSTAGES 3
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_kernel(ConvSplitArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // HSTAGES * HSTAGE = 144 KB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: see conv_igemm_kernel
+  const int NT = gridDim.y;
+  int mt_idx = blockIdx.x, nt_idx = blockIdx.y;
+  if (a.xcd_map) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int chunk = gridDim.x >> 3;
+    mt_idx = xcd * chunk + slot / NT;
+    nt_idx = slot - (slot / NT) * NT;
+  }
+  if (mt_idx * HBM_ >= a.M) return;
+  const int m0 = mt_idx * HBM_;
+  const int n0 = nt_idx * HBN_;
+
+  // ---- loader role.  One DMA instruction = 8 rows x 8 pieces of 16 B; lane l brings LDS slot (l & 7) of row
+  // (l >> 3), which holds source piece slot ^ ((row >> 1) & 7).  Wave w stages pixel rows 32w .. 32w+31 (4 DMAs) and
+  // weight rows 16w .. 16w+15 (2 DMAs) of every K-tile.
+  const int groups = a.Cin >> 5;            // 32-channel groups per pixel
+  const int taps = a.KH * a.KW;
+  const int nk = taps * groups;             // K-tiles: (channel group, tap), tap minor
+  const int px_bytes = groups * HROW;
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(a.in);
+  const unsigned char* w_b = reinterpret_cast<const unsigned char*>(a.w);
+  const int lr = lane >> 3, lslot = lane & 7;
+  const unsigned char* a_row[4];
+  int a_hi0[4], a_wi0[4];
+  int a_poff[4];                            // byte offset of this lane's source piece inside the 128-byte block
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 32 * wave + 8 * q + lr;   // row of the pixel tile
+    a_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
+    const int m = m0 + r;
+    if (m < a.M) {
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      a_hi0[q] = ho * a.stride - a.pad;
+      a_wi0[q] = wo * a.stride - a.pad;
+      a_row[q] = in_b + ((ptrdiff_t)img * a.Hi * a.Wi + (ptrdiff_t)a_hi0[q] * a.Wi + a_wi0[q]) * px_bytes + a_poff[q];
+    } else {
+      a_row[q] = in_b;
+      a_hi0[q] = -(1 << 28);
+      a_wi0[q] = -(1 << 28);
+    }
+  }
+  const unsigned char* b_row[2];
+  int b_poff[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = 16 * wave + 8 * q + lr;   // row of the weight tile
+    b_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
+    const int n = n0 + r;
+    b_row[q] = (n < a.Cout) ? w_b + (size_t)n * nk * HROW + b_poff[q] : nullptr;
+  }
+  const unsigned char* zero_b = reinterpret_cast<const unsigned char*>(a.zeros);
+
+  int kt_begin = 0, kt_end = nk;
+  if (a.splitk > 1) {
+    kt_begin = blockIdx.z * a.ktiles_per_split;
+    kt_end = min(nk, kt_begin + a.ktiles_per_split);
+  }
+
+  // K-tile walk (workgroup-uniform): channel group MAJOR, tap MINOR (the taps of one group re-read the same pixels
+  // shifted by one, back to back: L1/L2 hits), without divisions.
+  int t_kh = 0, t_kw = 0, t_g = 0, t_aoff = 0, t_boff = 0;
+  {
+    const int g = kt_begin / taps;
+    const int tap = kt_begin - g * taps;
+    t_g = g;
+    t_kh = tap / a.KW;
+    t_kw = tap - t_kh * a.KW;
+    t_aoff = (t_kh * a.Wi + t_kw) * px_bytes + g * HROW;
+    t_boff = kt_begin * HROW;
+  }
+  auto next_tile = [&]() {
+    ++t_kw;
+    t_aoff += px_bytes;
+    t_boff += HROW;
+    if (t_kw == a.KW) {
+      t_kw = 0;
+      ++t_kh;
+      t_aoff += (a.Wi - a.KW) * px_bytes;
+      if (t_kh == a.KH) {
+        t_kh = 0;
+        ++t_g;
+        t_aoff = t_g * HROW;
+      }
+    }
+  };
+  // 6 DMAs per wave and tile; the LDS destination is wave-uniform (+ lane * 16 by the hardware)
+  auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+    unsigned char* dst = lds + stage * HSTAGE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = (unsigned)(a_hi0[q] + t_kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + t_kw) < (unsigned)a.Wi;
+      const unsigned char* pa = ok ? a_row[q] + t_aoff : zero_b + a_poff[q];
+      __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + (32 * wave + 8 * q) * HROW), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const unsigned char* pb = b_row[q] ? b_row[q] + t_boff : zero_b + b_poff[q];
+      __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + HA_BYTES + (16 * wave + 8 * q) * HROW), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment reads: lane (fi, fh) of the 32x32x16 MFMA holds row fi, channels 8 fh .. 8 fh + 7 of the k-step:
+  // source piece c = 4 * piece + 2 * kstep + fh, LDS slot c ^ ((row >> 1) & 7); tile bases are multiples of 32 rows
+  const int fi = lane & 31, fh = lane >> 5;
+  const int fsw = (fi >> 1) & 7;
+  const int a_base = (wm * 64 + fi) * HROW;
+  const int b_base = HA_BYTES + (wn * 64 + fi) * HROW;
+  int foff[2][2];   // [piece][kstep] byte offset inside the row
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[p][s] = ((4 * p + 2 * s + fh) ^ fsw) * 16;
+
+  // D rows = output channels (weights are the MFMA's A operand), D columns = pixels: a lane ends up with 4
+  // consecutive channels of one pixel per register group (one vector store each in the epilogue).
+  auto multiply = [&](int stage) __attribute__((always_inline)) {
+    const unsigned char* Ab = lds + stage * HSTAGE + a_base;
+    const unsigned char* Bb = lds + stage * HSTAGE + b_base;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f16x8 xf[2][2], wf[2][2];   // [tile][piece]
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          xf[i][p] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * HROW + foff[p][s]);
+          wf[i][p] = *reinterpret_cast<const f16x8*>(Bb + i * 32 * HROW + foff[p][s]);
+        }
+      }
+      constexpr int PW[3] = {1, 0, 0};   // l_w h_x, h_w l_x, h_w h_x: small contributions first
+      constexpr int PX[3] = {0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][PW[t]], xf[0][PX[t]], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][PW[t]], xf[0][PX[t]], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][PW[t]], xf[1][PX[t]], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][PW[t]], xf[1][PX[t]], acc[1][1], 0, 0, 0);
+      }
+    }
+  };
+
+  const int ntile = kt_end - kt_begin;
+  // Prologue: tiles 0 and 1 in flight.  Past the end the walk stops and the same tile is fetched again (unused), so
+  // every wave always has exactly 6 DMAs per stage outstanding and the counted waits below stay exact.
+  issue_tile(0);
+  if (ntile > 1) next_tile();
+  issue_tile(1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int st_cur = 0, st_nxt = 2;   // stage holding tile j / stage to refill with tile j+2
+  for (int j = 0; j < ntile; ++j) {
+    if (j + 2 < ntile) next_tile();
+    issue_tile(st_nxt);                    // tile j+2 -> the stage tile j-1 was read from (everyone is past that barrier)
+    multiply(st_cur);
+    // tile j+1 has landed once all but the newest tile's DMAs are done; only then may anyone read it
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    st_nxt = st_cur;
+    st_cur = st_cur == 2 ? 0 : st_cur + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: column (= pixel) = lane&31, row (= channel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  bool range_bad = false;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = m0 + wm * 64 + mt * 32 + fi;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
+        if (n >= a.Cout) continue;
+        f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+        if (a.splitk > 1) {
+          *reinterpret_cast<f32x4*>(a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
+        } else {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = v[e] * sc[e] + sh[e];
+            v[e] = x > 0.f ? x : x * a.slope;
+          }
+          if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
+          else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.Cout + n) = v;
+        }
+      }
+    }
+  }
+  if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
+}
+
+// Deterministic split-K combine: sums the slabs in slab order, then the same epilogue; 4 channels per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_f16x2_kernel(ConvSplitArgs a) {
+  const size_t total4 = (size_t)a.M * a.Cout / 4;
+  const size_t slab = (size_t)a.M * a.Cout;
+  bool range_bad = false;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t e0 = idx * 4;
+    const size_t m = e0 / a.Cout;
+    const int n = (int)(e0 - m * a.Cout);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.splitk; ++z) v += *reinterpret_cast<const f32x4*>(a.partial + (size_t)z * slab + e0);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e] * sc[e] + sh[e];
+      v[e] = x > 0.f ? x : x * a.slope;
+    }
+    if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), m, n, a.Cout, v);
+    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + e0) = v;
+  }
+  if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
+}
+
+hipError_t launch_conv_f16x2(const ConvSplitArgs& a_in, hipStream_t st) {
+  ConvSplitArgs a = a_in;
+  const int mt = (a.M + HBM_ - 1) / HBM_;
+  a.xcd_map = mt >= 16;
+  dim3 grid(a.xcd_map ? (mt + 7) / 8 * 8 : mt, (a.Cout + HBN_ - 1) / HBN_, a.splitk > 1 ? a.splitk : 1);
+  const size_t lds = (size_t)HSTAGES * HSTAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(conv_f16x2_kernel, grid, dim3(512), lds, st, a);
+  if (a.splitk > 1) {
+    const size_t total4 = (size_t)a.M * a.Cout / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_f16x2_kernel, dim3(blocks), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+// fp32 [pixel][C] <-> P2, 4 channels per thread (API boundary of odevio_conv_block_fwd and tests; the encoder itself
+// never converts: every producer writes P2 directly).
+__global__ __launch_bounds__(256) void pair_pack_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, size_t pixels, int C,
+                                                        int* status) {
+  const size_t total4 = pixels * C / 4;
+  bool range_bad = false;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t e0 = idx * 4;
+    const size_t m = e0 / C;
+    const int n = (int)(e0 - m * C);
+    range_bad |= store_pair4(out, m, n, C, *reinterpret_cast<const f32x4*>(in + e0));
+  }
+  if (range_bad) status[ODEVIO_STATUS_RANGE] = 1;
+}
+
+__global__ __launch_bounds__(256) void pair_unpack_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, size_t pixels, int C) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const size_t total4 = pixels * C / 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t e0 = idx * 4;
+    const size_t m = e0 / C;
+    const int n = (int)(e0 - m * C);
+    const unsigned char* p = in + (m * (C >> 5) + (n >> 5)) * HROW + (n & 31) * 2;
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p), l = *reinterpret_cast<const f16x4*>(p + 64);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)h[e] + (float)l[e];
+    *reinterpret_cast<f32x4*>(out + e0) = v;
+  }
+}
+
+void launch_pair_pack(const float* in, void* out, size_t pixels, int C, int* status, hipStream_t st) {
+  int blocks = (int)std::min<size_t>((pixels * C / 4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(pair_pack_kernel, dim3(blocks), dim3(256), 0, st, in, reinterpret_cast<unsigned char*>(out), pixels, C, status);
+}
+void launch_pair_unpack(const void* in, float* out, size_t pixels, int C, hipStream_t st) {
+  int blocks = (int)std::min<size_t>((pixels * C / 4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(pair_unpack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(in), out, pixels, C);
+}

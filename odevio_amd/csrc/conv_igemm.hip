@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
               const float x = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
               v[e] = x > 0.f ? x : x * a.slope;
             }
-            if (a.out_split) store_split4(reinterpret_cast<unsigned char*>(a.out), opix, n, 64, v);
+            if (a.out_split) { if (store_pair4(reinterpret_cast<unsigned char*>(a.out), opix, n, 64, v)) a.status[ODEVIO_STATUS_RANGE] = 1; }
             else *reinterpret_cast<f32x4*>(orow + n) = v;
           }
         }
@@ -452,7 +452,7 @@ void launch_conv1(const Conv1Args& a, int n_cu, hipStream_t st) {
   const size_t lds = (size_t)(294 * 64 + 2 * C1_PATCH) * sizeof(float);  // 144,816 B
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   int grid = n_cu < a.n_tiles ? n_cu : a.n_tiles;
