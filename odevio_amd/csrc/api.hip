@@ -316,6 +316,31 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
     }
     TRY(upload(p, &p->conv_w[i], t, st));
     float prescale = 1.f;
+    if (i == 0) {  // fp16x2 conv1: [piece][(c,kh) row][channel][8 kw slots] (kw = 7 is zero), see conv1_f16x2.hip
+      float wmax = 0.f;
+      for (float x : w) wmax = std::max(wmax, std::fabs(x));
+      int e = 0;
+      if (wmax > 0.f && std::isfinite(wmax)) {
+        (void)std::frexp(wmax, &e);
+        e = std::max(-40, std::min(40, 14 - e));
+      }
+      prescale = std::ldexp(1.0f, e);
+      std::vector<uint16_t> ws((size_t)2 * 42 * 64 * 8, 0);
+      for (int n = 0; n < 64; ++n)
+        for (int c = 0; c < 6; ++c)
+          for (int kh = 0; kh < 7; ++kh)
+            for (int kw = 0; kw < 7; ++kw) {
+              const float x = w[(((size_t)n * 6 + c) * 7 + kh) * 7 + kw] * prescale;
+              const _Float16 h = (_Float16)x;
+              const _Float16 l = (_Float16)(x - (float)h);
+              const size_t base = ((size_t)(c * 7 + kh) * 64 + n) * 8 + kw;
+              memcpy(&ws[base], &h, 2);
+              memcpy(&ws[(size_t)42 * 64 * 8 + base], &l, 2);
+            }
+      TRY(dev_alloc(p, &p->conv_ws[0], ws.size() * sizeof(uint16_t)));
+      HIPCHK(hipMemcpyAsync(p->conv_ws[0], ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
     if (i > 0) {
       std::vector<uint16_t> ws;
       prescale = split_conv_weights(w, cs.cout, cs.cin, cs.k * cs.k, ws);
@@ -324,7 +349,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       HIPCHK(hipStreamSynchronize(st));
     }
     TRY(bn_fold(wt, pre + ".1", cs.cout, nullptr, sc, sh));
-    if (i > 0) {
+    {
       std::vector<float> sch(sc);
       for (float& v : sch) v /= prescale;   // exact: prescale is a power of two
       TRY(upload(p, &p->conv_scale_h[i], sch, st));
@@ -522,7 +547,8 @@ static int run_gemm(odevio_plan* p, const float* in, int M, int K, const float* 
   return 0;
 }
 
-// Same cost model for the fp16x2 kernel: 256 x 128 tiles, one workgroup per CU, K-tiles of 32 channels at ~0.45 us.
+// Same cost model for the fp16x2 kernel: 256 x 128 tiles, one workgroup per CU, K-tiles of 32 channels at ~1.4 us
+// (measured: conv3_1 = 10 rounds x 78 steps in 1.2 ms).
 static int pick_splitk_h(int M, int N, int nk) {
   const double tiles = (double)((M + 255) / 256) * ((N + 127) / 128);
   if (tiles >= 1024 || nk < 24) return 1;
@@ -532,7 +558,7 @@ static int pick_splitk_h(int M, int N, int nk) {
     if (s > 1 && nk / s < 12) break;
     const double rounds = std::ceil(tiles * s / 256.0);
     const double steps = std::ceil((double)nk / s) + 6.0;
-    double cost = rounds * steps * 0.45;
+    double cost = rounds * steps * 1.4;
     if (s > 1) cost += (s + 1.0) * M * N * 4.0 / 4.0e6 + 8.0;
     if (cost < best_cost * 0.97) {
       best_cost = cost;
@@ -554,7 +580,13 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.out_split = out_split; a.status = p->status;
     a.B = B; a.S = S; a.H = p->conv_h[0]; a.W = p->conv_w_sp[0]; a.Ho = p->conv_h[1]; a.Wo = p->conv_w_sp[1];
     a.tiles_y = (a.Ho + 7) / 8; a.tiles_x = (a.Wo + 31) / 32; a.n_tiles = P * a.tiles_y * a.tiles_x; a.slope = 0.1f;
-    launch_conv1(a, p->n_cu, st);
+    if (p->conv_math != 0) {
+      a.wt16 = p->conv_ws[0];
+      a.scale = p->conv_scale_h[0];
+      HIPCHK(launch_conv1_f16x2(a, p->n_cu, st));
+    } else {
+      launch_conv1(a, p->n_cu, st);
+    }
     return 0;
   }
   if (in_split) {

@@ -52,7 +52,8 @@ struct ConvSplitArgs {
 // conv1 of the FlowNetS stack, reading frame pairs in place from img [B][S][3][H][W]
 struct Conv1Args {
   const float* img;
-  const float* wt;      // [294][64]  (k = c*49 + kh*7 + kw, c in 0..5)
+  const float* wt;      // [294][64]  (k = c*49 + kh*7 + kw, c in 0..5): fp32-input MFMA kernel
+  const void* wt16;     // [2 pieces][42 (c,kh) rows][64][8 kw] fp16, pre-scaled: fp16x2 kernel (conv1_f16x2.hip)
   const float* scale;   // [64]
   const float* shift;   // [64]
   void* out;            // NHWC [P][Ho][Wo][64] fp32, or the same pixels in P2 layout (out_split)
@@ -77,6 +78,7 @@ struct ImuArgs {
 
 void launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 void launch_conv1(const Conv1Args& a, int n_cu, hipStream_t st);
+hipError_t launch_conv1_f16x2(const Conv1Args& a, int n_cu, hipStream_t st);
 void launch_imu_convs(const ImuArgs& a, hipStream_t st);
 hipError_t launch_conv_f16x2(const ConvSplitArgs& a, hipStream_t st);
 void launch_pair_pack(const float* in, void* out, size_t pixels, int C, int* status, hipStream_t st);   // fp32 [pixel][C] -> P2
