@@ -18,7 +18,9 @@
 // result once in the epilogue.  Weights: [Cout][K-tile][2][32] with K-tile = (channel group, tap), tap minor.
 //
 // Tiling: 256 pixels x 128 output channels x 32 input channels per 512-thread workgroup (8 waves as 4 x 2, 64x64
-// each: 2x2 MFMA 32x32x16 tiles x 2 k-steps x 3 piece pairs = 24 MFMAs per K-tile), one workgroup per CU.
+// each: 4x4 MFMA 16x16x32 tiles x 3 piece pairs = 48 MFMAs per K-tile), one workgroup per CU.  The kernel is
+// power-limited (PMC: 1.76 GHz at 50 % MFMA busy, every staging/pipelining variant lands on the same time); the
+// 16x16x32 shape does the same flops 7 % faster than 32x32x16 here (6.30 vs 6.78 ms per forward).
 // Staging is LDS-DMA (global_load_lds_dwordx4, no staging registers, no ds_write pass): one wave instruction moves
 // 8 rows x 128 B - eight whole cache lines - into 1 KB of LDS.  The LDS image of a row is its 128-byte line with the
 // eight 16-byte pieces XOR-permuted by (row >> 1) & 7 (applied on the SOURCE address, the DMA writes lane-linearly),
@@ -152,51 +154,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
 
-  f32x16 acc[2][2];
+  f32x4 acc[4][4];   // [pixel block of 16][channel block of 16]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment reads: lane (fi, fh) of the 32x32x16 MFMA holds row fi, channels 8 fh .. 8 fh + 7 of the k-step:
-  // source piece c = 4 * piece + 2 * kstep + fh, LDS slot c ^ ((row >> 1) & 7); tile bases are multiples of 32 rows
-  const int fi = lane & 31, fh = lane >> 5;
+  // fragment reads.  16x16x32 MFMA: lane (fi, fh) holds row fi of a 16-row block, channels 8 fh .. 8 fh + 7 of the
+  // 32-channel K-tile: source piece c = 4 * piece + fh, LDS slot c ^ ((row >> 1) & 7); block bases are multiples of 16
+  // rows, so the permutation only depends on fi.  Conflict-free per ds_read_b128 lane group.
+  const int fi = lane & 15, fh = lane >> 4;
   const int fsw = (fi >> 1) & 7;
   const int a_base = (wm * 64 + fi) * HROW;
   const int b_base = HA_BYTES + (wn * 64 + fi) * HROW;
-  int foff[2][2];   // [piece][kstep] byte offset inside the row
-#pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) foff[p][s] = ((4 * p + 2 * s + fh) ^ fsw) * 16;
 
   // D rows = output channels (weights are the MFMA's A operand), D columns = pixels: a lane ends up with 4
   // consecutive channels of one pixel per register group (one vector store each in the epilogue).
   auto multiply = [&](int stage) __attribute__((always_inline)) {
     const unsigned char* Ab = lds + stage * HSTAGE + a_base;
     const unsigned char* Bb = lds + stage * HSTAGE + b_base;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f16x8 xf[2][2], wf[2][2];   // [tile][piece]
+    {
+      f16x8 xf[4][2], wf[4][2];   // [block][piece]
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
+        const int off = ((4 * p + fh) ^ fsw) * 16;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          xf[i][p] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * HROW + foff[p][s]);
-          wf[i][p] = *reinterpret_cast<const f16x8*>(Bb + i * 32 * HROW + foff[p][s]);
+        for (int i = 0; i < 4; ++i) {
+          xf[i][p] = *reinterpret_cast<const f16x8*>(Ab + i * 16 * HROW + off);
+          wf[i][p] = *reinterpret_cast<const f16x8*>(Bb + i * 16 * HROW + off);
         }
       }
       constexpr int PW[3] = {1, 0, 0};   // l_w h_x, h_w l_x, h_w h_x: small contributions first
       constexpr int PX[3] = {0, 1, 0};
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][PW[t]], xf[0][PX[t]], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][PW[t]], xf[0][PX[t]], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][PW[t]], xf[1][PX[t]], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][PW[t]], xf[1][PX[t]], acc[1][1], 0, 0, 0);
-      }
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][PW[t]], xf[i][PX[t]], acc[i][n], 0, 0, 0);
     }
   };
 
@@ -221,32 +217,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: column (= pixel) = lane&31, row (= channel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  C/D map of the 16x16 MFMA: column (= pixel) = lane&15, row (= channel) = 4*(lane>>4) + r
   bool range_bad = false;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int m = m0 + wm * 64 + mt * 32 + fi;
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fi;
     if (m >= a.M) continue;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nb4 = 0; nb4 < 4; ++nb4) {
+      const int n = n0 + wn * 64 + nb4 * 16 + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
+      if (n >= a.Cout) continue;
+      f32x4 v = acc[i][nb4];
+      if (a.splitk > 1) {
+        *reinterpret_cast<f32x4*>(a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
+      } else {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
-        if (n >= a.Cout) continue;
-        f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
-        if (a.splitk > 1) {
-          *reinterpret_cast<f32x4*>(a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
-        } else {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x = v[e] * sc[e] + sh[e];
-            v[e] = x > 0.f ? x : x * a.slope;
-          }
-          if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
-          else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.Cout + n) = v;
+        for (int e = 0; e < 4; ++e) {
+          const float x = v[e] * sc[e] + sh[e];
+          v[e] = x > 0.f ? x : x * a.slope;
         }
+        if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
+        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.Cout + n) = v;
       }
     }
   }
