@@ -146,6 +146,13 @@ int odevio_forward(odevio_plan* plan, const float* img, const float* imu, int32_
 int odevio_path_accu(const void* poses6, int32_t is_f64, const int64_t* offsets, int32_t n_drives, const double* carry,
                      double* mats, void* stream);
 
+/* The same forward from the loader's uint8 frames (reference src/data/KITTI_eval.py:97-110, src/data/utils.py:355-374:
+ * PIL image -> resize -> ToTensor() - 0.5): img_u8 [B,S,H,W,3] uint8 (HWC, already resized to img_h x img_w); the
+ * normalisation float(byte) / 255 - 0.5 is fused into the encoder's ingest pass (69 MB instead of 277 MB at B = 16).
+ * Model types ode-rnn / rnn; needs the default fp16x2 encoder. */
+int odevio_forward_u8(odevio_plan* plan, const uint8_t* img_u8, const float* imu, int32_t T, const float* ts,
+                      const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream);
+
 /* Per-stage timing of odevio_forward with HIP events recorded on the caller's stream (used by bench.py for
  * the roofline figures).  Stages: 0 conv1, 1 conv2..conv6 (implicit-GEMM kernel), 2 visual head,
  * 3 inertial encoder + fusion, 4 persistent ODE-RNN integrator, 5 pose regressor. */

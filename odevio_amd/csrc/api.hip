@@ -55,7 +55,7 @@ struct odevio_plan {
   void* conv_ws[9] = {};   // conv2..conv6 weights as two fp16 pieces (conv_f16x2.hip), [Cout][K-tile][2][32], pre-scaled
   float* conv_scale_h[9] = {};  // BatchNorm scale with the weights' power-of-two pre-scale folded back in
   int conv_math = 1;       // 1: fp16x2 operand split on the fp16 MFMA (default); 0: fp32-input MFMA (ODEVIO_CONV_MATH=f32)
-  DevBuf pack_tmp;
+  DevBuf pack_tmp, ingest;
   void* zero_page = nullptr;  // what the split kernel's LDS-DMA reads for taps outside the image
   float* conv_scale[9] = {};
   float* conv_shift[9] = {};
@@ -210,7 +210,7 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (!p) return;
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->hT_scratch, &p->cde_ws, &p->pack_tmp})
+                    &p->hT_scratch, &p->cde_ws, &p->pack_tmp, &p->ingest})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
@@ -571,7 +571,7 @@ static int pick_splitk_h(int M, int N, int nk) {
 // One encoder block.  Activations between blocks live in the P2 split layout when the fp16x2 kernel is in use
 // (in_split / out_split); fp32 NHWC otherwise.
 static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void* out, bool in_split, bool out_split,
-                      hipStream_t st) {
+                      hipStream_t st, bool in_u8 = false) {
   const int P = B * (S - 1);
   const ConvSpec& cs = kConvs[i];
   if (i == 0) {
@@ -581,10 +581,20 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.B = B; a.S = S; a.H = p->conv_h[0]; a.W = p->conv_w_sp[0]; a.Ho = p->conv_h[1]; a.Wo = p->conv_w_sp[1];
     a.tiles_y = (a.Ho + 7) / 8; a.tiles_x = (a.Wo + 31) / 32; a.n_tiles = P * a.tiles_y * a.tiles_x; a.slope = 0.1f;
     if (p->conv_math != 0) {
+      // frames -> zero-bordered fp16-piece planes once per forward (also the uint8 entry: byte / 255 - 0.5)
+      IngestArgs g{};
+      g.src = in; g.src_u8 = in_u8; g.n_frames = B * S; g.H = a.H; g.W = a.W;
+      g.Hp = 16 * a.tiles_y + 8; g.Wp = 64 * a.tiles_x + 8;
+      int rc = ensure(p->ingest, (size_t)g.n_frames * 3 * g.Hp * g.Wp);   // 2 pieces x 2 bytes = one float per pixel
+      if (rc) return rc;
+      g.planes = p->ingest.p;
+      launch_ingest(g, st);
+      a.planes = g.planes; a.zeros = p->zero_page; a.Hp = g.Hp; a.Wp = g.Wp;
       a.wt16 = p->conv_ws[0];
       a.scale = p->conv_scale_h[0];
       HIPCHK(launch_conv1_f16x2(a, p->n_cu, st));
     } else {
+      if (in_u8) return fail(ODEVIO_ERR_UNSUPPORTED, "uint8 frames need the fp16x2 encoder (unset ODEVIO_CONV_MATH=f32)");
       launch_conv1(a, p->n_cu, st);
     }
     return 0;
@@ -638,13 +648,14 @@ static int ensure_act(odevio_plan* p, int P) {
   return ensure(p->actB, nB);
 }
 
-static int image_encoder(odevio_plan* p, const float* img, int B, int S, float* fv, int ld_fv, hipStream_t st) {
+static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* fv, int ld_fv, hipStream_t st,
+                         bool img_u8 = false) {
   const int P = B * (S - 1);
   int rc;
   if ((rc = ensure_act(p, P))) return rc;
   const bool split = p->conv_math != 0;  // conv1 .. conv5_1 hand their output over in the P2 split layout
   stage_mark(p, 0, st);
-  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, false, split, st))) return rc;
+  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, false, split, st, img_u8))) return rc;
   stage_mark(p, 1, st);
   float* cur = p->actA.p;
   for (int i = 1; i < 9; ++i) {
@@ -1029,9 +1040,23 @@ extern "C" int odevio_cde_fwd(odevio_plan* p, const float* obs, int32_t B, int32
   return regress(p, sol, B * n_out, poses, st);
 }
 
+static int forward_any(odevio_plan* p, const void* img, bool img_u8, const float* imu, int32_t T, const float* ts,
+                       const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream);
+
 extern "C" int odevio_forward(odevio_plan* p, const float* img, const float* imu, int32_t T, const float* ts,
                               const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats,
                               void* stream) {
+  return forward_any(p, img, false, imu, T, ts, hc, B, S, poses, h_T, stats, stream);
+}
+
+extern "C" int odevio_forward_u8(odevio_plan* p, const uint8_t* img, const float* imu, int32_t T, const float* ts,
+                                 const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats,
+                                 void* stream) {
+  return forward_any(p, img, true, imu, T, ts, hc, B, S, poses, h_T, stats, stream);
+}
+
+static int forward_any(odevio_plan* p, const void* img, bool img_u8, const float* imu, int32_t T, const float* ts,
+                       const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream) {
   ARGCHK(p && img && imu && ts && poses && h_T && B > 0 && S > 1, "odevio_forward: bad argument");
   if ((T - 1) / 10 != S - 1) return fail(ODEVIO_ERR_BAD_ARG, "imu length %d does not give %d frame pairs", T, S - 1);
   hipStream_t st = (hipStream_t)stream;
@@ -1039,7 +1064,7 @@ extern "C" int odevio_forward(odevio_plan* p, const float* img, const float* imu
   int rc;
   if ((rc = ensure(p->fcat, (size_t)P * F)) || (rc = ensure(p->fused, (size_t)P * F))) return rc;
   // encoders write straight into the concatenated feature rows (torch.cat of FusionModule.py:19 is free)
-  if ((rc = image_encoder(p, img, B, S, p->fcat.p, F, st))) return rc;
+  if ((rc = image_encoder(p, img, B, S, p->fcat.p, F, st, img_u8))) return rc;
   if ((rc = imu_encoder(p, imu, B, T, p->fcat.p + p->cfg.v_f_len, F, st))) return rc;
   const float* fused = p->fcat.p;
   if (p->cfg.fuse_method != ODEVIO_FUSE_CAT) {

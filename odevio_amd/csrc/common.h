@@ -50,8 +50,19 @@ struct ConvSplitArgs {
 };
 
 // conv1 of the FlowNetS stack, reading frame pairs in place from img [B][S][3][H][W]
+// Frames -> zero-bordered fp16-piece planes [frame][3][2][Hp][Wp] for conv1_f16x2_kernel (conv1_f16x2.hip)
+struct IngestArgs {
+  const void* src;      // fp32 [frame][3][H][W], or uint8 [frame][H][W][3] (src_u8: normalised as byte / 255 - 0.5)
+  int src_u8;
+  void* planes;
+  int n_frames, H, W, Hp, Wp;
+};
+
 struct Conv1Args {
-  const float* img;
+  const float* img;     // fp32-input MFMA kernel only
+  const void* planes;   // ingested frames (fp16x2 kernel): Hp = 16 tiles_y + 8 rows, Wp = 64 tiles_x + 8 columns
+  const void* zeros;
+  int Hp, Wp;
   const float* wt;      // [294][64]  (k = c*49 + kh*7 + kw, c in 0..5): fp32-input MFMA kernel
   const void* wt16;     // [2 pieces][42 (c,kh) rows][64][8 kw] fp16, pre-scaled: fp16x2 kernel (conv1_f16x2.hip)
   const float* scale;   // [64]
@@ -79,6 +90,7 @@ struct ImuArgs {
 void launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 void launch_conv1(const Conv1Args& a, int n_cu, hipStream_t st);
 hipError_t launch_conv1_f16x2(const Conv1Args& a, int n_cu, hipStream_t st);
+void launch_ingest(const IngestArgs& a, hipStream_t st);
 void launch_imu_convs(const ImuArgs& a, hipStream_t st);
 hipError_t launch_conv_f16x2(const ConvSplitArgs& a, hipStream_t st);
 void launch_pair_pack(const float* in, void* out, size_t pixels, int C, int* status, hipStream_t st);   // fp32 [pixel][C] -> P2

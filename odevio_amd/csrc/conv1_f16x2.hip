@@ -11,8 +11,11 @@
 //             input pixels (2*ox .. 2*ox + 7) of one patch row: one 16-byte run of the patch, no gather.
 //             42 rows -> 21 k-steps (the MFMA's two lane halves take rows 2s and 2s + 1).
 //   weights : LDS [piece][42 rows][64 channels][8 kw] fp16 (16 B per lane and fragment, contiguous over lanes)
-//   patch   : LDS [piece][6][21][72] fp16, double-buffered; the next tile's pixels are loaded into registers before the
-//             MFMA loop and split / stored after it.
+//   patch   : LDS [piece][6][21][72] fp16, double-buffered, filled by LDS-DMA from the INGESTED frames: ingest_kernel
+//             (below) turns the fp32 (or uint8) frames once per forward into zero-bordered fp16-piece planes
+//             [frame][channel][piece][Hp][Wp], so a patch row is one aligned 144-byte run that needs no bounds check,
+//             no conversion and no ds_write: 36 DMA instructions per tile (7 rows x 9 x 16 B each) instead of ~900
+//             load/convert/store instructions - with one wave per SIMD those set the kernel's time, not the MFMAs.
 //   wave w  : output rows 2w, 2w + 1 of the tile x 32 columns x 64 channels = 2 x 2 MFMA tiles; 12 MFMAs per k-step,
 //             fragments of k-step s + 1 are read while k-step s is multiplied.
 #include "common.h"
@@ -30,12 +33,62 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define H1_ROWS (6 * H1_PH)               // 126 (channel, row) lines
 #define H1_PAIRS (H1_ROWS * (H1_PWU / 2)) // 4410 column pairs per patch
 #define H1_PAIRS_PER_THREAD ((H1_PAIRS + 255) / 256)   // 18
-#define H1_PIECE_BYTES (H1_ROWS * H1_PW * 2)           // 18144
-#define H1_PATCH_BYTES (2 * H1_PIECE_BYTES)            // 36288
+#define H1_PIECE_BYTES (H1_ROWS * H1_PW * 2 + 16)      // 18144 + one 16-byte slot for the 64th lane of the last DMA
+#define H1_PATCH_BYTES (2 * H1_PIECE_BYTES)            // 36320
 #define H1_KROWS 42
 #define H1_WPIECE_BYTES (H1_KROWS * 64 * 16)           // 43008
 #define H1_W_BYTES (2 * H1_WPIECE_BYTES)               // 86016
-#define H1_LDS (H1_W_BYTES + 2 * H1_PATCH_BYTES)       // 158592
+#define H1_LDS (H1_W_BYTES + 2 * H1_PATCH_BYTES)       // 158656
+#define H1_DMA_PER_WAVE 9                              // 2 pieces x 18 row groups of 7 rows, over 4 waves
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// fp32 [frame][3][H][W] or uint8 [frame][H][W][3] frames -> fp16 pieces [frame][3][2][Hp][Wp] with a zero border:
+// padded row yp = y + 3, padded column xp = x + 3.  uint8 input is normalised like the reference's loader
+// (ToTensor() - 0.5, src/data/utils.py:359; KITTI_eval.py:100-103): float(byte) / 255 - 0.5 in fp32.
+// One thread = 8 consecutive padded columns of one (plane, row): two 16-byte stores.
+__global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
+  const int chunks = a.Wp >> 3;
+  const size_t total = (size_t)a.n_frames * 3 * a.Hp * chunks;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % chunks);
+    size_t r = idx / chunks;
+    const int yp = (int)(r % a.Hp);
+    const size_t plane = r / a.Hp;           // frame * 3 + c
+    const int y = yp - 3, x0 = 8 * k - 3;
+    const bool oky = (unsigned)y < (unsigned)a.H;
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int x = x0 + e;
+      const bool ok = oky && (unsigned)x < (unsigned)a.W;
+      float v = 0.f;
+      if (a.src_u8) {
+        const size_t frame = plane / 3;
+        const int c = (int)(plane - frame * 3);
+        const unsigned char* sp = reinterpret_cast<const unsigned char*>(a.src);
+        const unsigned char b = sp[ok ? ((frame * a.H + y) * a.W + x) * 3 + c : 0];
+        v = ok ? (float)b / 255.0f - 0.5f : 0.f;
+      } else {
+        const float* sp = reinterpret_cast<const float*>(a.src);
+        const float f = sp[ok ? (plane * a.H + y) * a.W + x : 0];
+        v = ok ? f : 0.f;
+      }
+      h[e] = (_Float16)v;
+      l[e] = (_Float16)(v - (float)h[e]);
+    }
+    _Float16* dst = reinterpret_cast<_Float16*>(a.planes) + ((plane * 2) * a.Hp + yp) * (size_t)a.Wp + 8 * k;
+    *reinterpret_cast<f16x8*>(dst) = h;
+    *reinterpret_cast<f16x8*>(dst + (size_t)a.Hp * a.Wp) = l;
+  }
+}
+
+void launch_ingest(const IngestArgs& a, hipStream_t st) {
+  const size_t total = (size_t)a.n_frames * 3 * a.Hp * (a.Wp >> 3);
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, st, a);
+}
 
 __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -55,64 +108,32 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
   }
 
   const int tiles_per_pair = a.tiles_y * a.tiles_x;
-  const size_t plane = (size_t)a.H * a.W;
-  float st0[H1_PAIRS_PER_THREAD], st1[H1_PAIRS_PER_THREAD];   // the next tile's pixels, two per slot
-
-  // The next tile's patch is fetched and stored PIECEWISE inside the MFMA loop (one wave per SIMD: nothing else would
-  // hide its ~2000 VALU/memory instructions): column pairs 2s, 2s+1 are loaded in k-step s (s < 9) and split / stored
-  // in k-step s + 10, ~4000 cycles later.  Pair idx = tid + 256 j of the [126][35] pair grid; the walk state advances
-  // without divisions: +256 = +7 lines +11 pairs.  (A per-thread offset table with a bounds-check-free branch for
-  // interior tiles was measured 35 % SLOWER: the branch puts every pair's loads in their own basic block and hipcc
-  // opens each with s_waitcnt vmcnt(0).)
-  const float* pl_base = a.img;
-  int pl_gy0 = 0, pl_gx0 = 0, pl_xp = 0, pl_yy = 0, ps_xp = 0, ps_yy = 0;
-  auto patch_begin = [&](int tile) __attribute__((always_inline)) {
+  // Patch staging by LDS-DMA.  The 36 instructions of a tile (piece p, row group q: rows 7q .. 7q+6, 9 x 16 B each) are
+  // dealt to the waves 9 apiece; which bytes a lane brings does not depend on the tile: its offset from the tile's
+  // corner is computed once.  Lane 63 lands 16 bytes behind its group: it brings the first 16 bytes of the NEXT row
+  // (what the next instruction puts there anyway), or zeros into the spare slot behind the piece.
+  const size_t plane_bytes = (size_t)a.Hp * a.Wp * 2;          // one (channel, piece) plane
+  const unsigned char* planes_b = reinterpret_cast<const unsigned char*>(a.planes);
+  int d_off[H1_DMA_PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < H1_DMA_PER_WAVE; ++k) {
+    const int g = H1_DMA_PER_WAVE * wave + k, p = g / 18, q = g - 18 * p;
+    const int r = 7 * q + (lane == 63 ? 7 : lane / 9), pc = lane == 63 ? 0 : lane % 9;
+    const int c = r / H1_PH, y = r - c * H1_PH;
+    d_off[k] = r < H1_ROWS ? (int)((c * 2 + p) * plane_bytes) + y * a.Wp * 2 + pc * 16 : -1;
+  }
+  auto issue_patch_dma = [&](const unsigned char* corner, unsigned char* Pdst, int k) __attribute__((always_inline)) {
+    const int g = H1_DMA_PER_WAVE * wave + k, p = g / 18, q = g - 18 * p;
+    const unsigned char* src = d_off[k] >= 0 ? corner + d_off[k] : reinterpret_cast<const unsigned char*>(a.zeros);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Pdst + p * H1_PIECE_BYTES + 7 * q * H1_PW * 2), 16, 0, 0);
+  };
+  auto tile_corner = [&](int tile) __attribute__((always_inline)) {
     const int pair = tile / tiles_per_pair;
     const int t = tile - pair * tiles_per_pair;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int b = pair / (a.S - 1), fr = pair - b * (a.S - 1);
-    pl_base = a.img + ((size_t)b * a.S + fr) * 3 * plane;
-    pl_gy0 = 2 * ty * H1_TH - 3;
-    pl_gx0 = 2 * tx * H1_TW - 3;
-    pl_xp = ps_xp = tid % (H1_PWU / 2);
-    pl_yy = ps_yy = tid / (H1_PWU / 2);   // yy = c*21 + y
-  };
-  auto load_pair = [&](int j) __attribute__((always_inline)) {
-    const int c = pl_yy / H1_PH, y = pl_yy - c * H1_PH;  // constant divisor: one mul-hi
-    const int gy = pl_gy0 + y, gx = pl_gx0 + 2 * pl_xp;
-    const bool oky = pl_yy < H1_ROWS && (unsigned)gy < (unsigned)a.H;
-    const bool ok0 = oky && (unsigned)gx < (unsigned)a.W;
-    const bool ok1 = oky && (unsigned)(gx + 1) < (unsigned)a.W;
-    const float* row = pl_base + c * plane + (size_t)gy * a.W;
-    // unconditional loads from clamped addresses, zero fill by select (see conv_igemm_kernel)
-    const float v0 = *(ok0 ? row + gx : pl_base);
-    const float v1 = *(ok1 ? row + gx + 1 : pl_base);
-    st0[j] = ok0 ? v0 : 0.f;
-    st1[j] = ok1 ? v1 : 0.f;
-    pl_xp += 256 % (H1_PWU / 2);
-    pl_yy += 256 / (H1_PWU / 2);
-    if (pl_xp >= H1_PWU / 2) {
-      pl_xp -= H1_PWU / 2;
-      ++pl_yy;
-    }
-  };
-  auto store_pair = [&](unsigned char* Ps, int j) __attribute__((always_inline)) {
-    if (ps_yy < H1_ROWS) {
-      f16x2 h, l;
-      h[0] = (_Float16)st0[j];
-      h[1] = (_Float16)st1[j];
-      l[0] = (_Float16)(st0[j] - (float)h[0]);
-      l[1] = (_Float16)(st1[j] - (float)h[1]);
-      const int off = (ps_yy * H1_PW + 2 * ps_xp) * 2;
-      *reinterpret_cast<f16x2*>(Ps + off) = h;
-      *reinterpret_cast<f16x2*>(Ps + H1_PIECE_BYTES + off) = l;
-    }
-    ps_xp += 256 % (H1_PWU / 2);
-    ps_yy += 256 / (H1_PWU / 2);
-    if (ps_xp >= H1_PWU / 2) {
-      ps_xp -= H1_PWU / 2;
-      ++ps_yy;
-    }
+    // padded row of patch row 0 = 16 ty - 3 + 3, padded column of patch column 0 = 64 tx - 3 + 3
+    return planes_b + ((size_t)b * a.S + fr) * 6 * plane_bytes + ((size_t)(2 * ty * H1_TH) * a.Wp + 2 * tx * H1_TW) * 2;
   };
 
   // lane bases.  Activations: output row 2*wave (+1), column fi -> patch row 4*wave (+2) + kh, columns 2*fi .. 2*fi+7.
@@ -123,17 +144,25 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
   int tile = blockIdx.x;
   int buf = 0;
   if (tile < a.n_tiles) {
-    patch_begin(tile);
+    const unsigned char* corner = tile_corner(tile);
 #pragma unroll
-    for (int j = 0; j < H1_PAIRS_PER_THREAD; ++j) load_pair(j);
-#pragma unroll
-    for (int j = 0; j < H1_PAIRS_PER_THREAD; ++j) store_pair(Ps0, j);
+    for (int k = 0; k < H1_DMA_PER_WAVE; ++k) issue_patch_dma(corner, Ps0, k);
   }
-  __syncthreads();
+  __syncthreads();   // drains the DMAs (vmcnt(0)) and the filter-bank copy
+  // BatchNorm scale / shift of this lane's 32 channels, once (the epilogue runs at one wave per SIMD: every load it
+  // does not have to wait for counts)
+  f32x4 e_sc[2][4], e_sh[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      e_sc[nt][g] = *reinterpret_cast<const f32x4*>(a.scale + nt * 32 + 8 * g + 4 * fh);
+      e_sh[nt][g] = *reinterpret_cast<const f32x4*>(a.shift + nt * 32 + 8 * g + 4 * fh);
+    }
   for (; tile < a.n_tiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
     const bool more = next < a.n_tiles;
-    patch_begin(more ? next : tile);     // the last tile re-stages itself (unused): branch-free loop body
+    const unsigned char* corner = tile_corner(more ? next : tile);   // the last tile re-stages itself (unused): branch-free body
     const unsigned char* Ps = buf ? Ps1 : Ps0;
     unsigned char* Pn = buf ? Ps0 : Ps1;
     f32x16 acc[2][2];
@@ -168,20 +197,9 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
     for (int s = 0; s < 21; ++s) {
       const int cur = s & 1;
       if (s + 1 < 21) read_frags(cur ^ 1, s + 1);
-#ifndef EXP_C1_NOSTAGE
-      if (s < 9) {
-        load_pair(2 * s);
-        load_pair(2 * s + 1);
-      } else if (s >= 10 && s < 19) {
-        store_pair(Pn, 2 * (s - 10));
-        store_pair(Pn, 2 * (s - 10) + 1);
-      }
-#endif
+      if (s < H1_DMA_PER_WAVE) issue_patch_dma(corner, Pn, s);   // next tile's patch, one DMA per k-step
       constexpr int PW[3] = {1, 0, 0};   // l_w h_x, h_w l_x, h_w h_x
       constexpr int PX[3] = {0, 1, 0};
-#ifdef EXP_C1_NOMFMA
-      if (s == 0)
-#endif
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         // weights as the MFMA's A operand: channels land on the register axis (vector stores below)
@@ -204,7 +222,12 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
       bool range_bad = false;
       if (a.out_split) {
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        __syncthreads();   // every wave is done reading this tile's patch
+        // Every wave is done reading this tile's patch and has its share of the NEXT patch in LDS (own DMAs: vmcnt(0);
+        // they were issued in k-steps 0..8).  Raw barriers from here on: a __syncthreads() would also wait for the
+        // global stores below, i.e. put an HBM write round trip between every two tiles (1.34 GB leave this kernel).
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         unsigned char* stg = const_cast<unsigned char*>(Ps) + wave * (H1_PATCH_BYTES / 4);   // 9072 B >= 32 * 264
         unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
 #pragma unroll
@@ -214,14 +237,12 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
           for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const int n = nt * 32 + 8 * g + 4 * fh;
-              const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-              const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+              const f32x4 sc = e_sc[nt][g], sh = e_sh[nt][g];
               f16x4 h, l;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 float x = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
-                x = x > 0.f ? x : x * a.slope;
+                x = fmaxf(x, x * a.slope);   // LeakyReLU for 0 < slope < 1
                 range_bad |= !(fabsf(x) <= 65504.f);
                 h[e] = (_Float16)x;
                 l[e] = (_Float16)(x - (float)h[e]);
@@ -242,11 +263,7 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
               const unsigned char* q = stg + px * 264 + within;
               const u32x2 lo = *reinterpret_cast<const u32x2*>(q);
               const u32x2 hi = *reinterpret_cast<const u32x2*>(q + 8);
-#ifdef EXP_C1_NOSTORE
-              if (px < px_valid && lo[0] == 0x12345678u) {
-#else
               if (px < px_valid) {
-#endif
                 u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
                 *reinterpret_cast<u32x4*>(outb + opix0 * 256 + o) = v;
               }
@@ -282,7 +299,15 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
       if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
     }
     buf ^= 1;
-    __syncthreads();
+    // the staging area (this tile's patch buffer) is refilled by next iteration's DMAs: all LDS reads must be done.
+    // The output stores stay in flight.
+    if (a.out_split) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
   }
 }
 

@@ -240,12 +240,25 @@ class DeepVIO(nn.Module):
     def forward(self, img, imu, timestamps, hc=None):
         """img [B,S,3,H,W], imu [B,10(S-1)+1(+tail),6], timestamps [B,S], hc None | [L,B,F] -> (poses [B,S-1,6], h_T [L,B,F])."""
         self._ensure_plan()
+        if img.dtype == torch.uint8 and (self.opt.model_type == "cde" or self.opt.fuse_method == "hard"):
+            raise ValueError("uint8 frames are supported for model_type ode-rnn / rnn with cat or soft fusion")
         if self.opt.model_type == "cde":
             return self.pose_cde(self.image_encoder(img), self.imu_encoder(imu), timestamps, hc)
         if self.opt.fuse_method == "hard":
             fv, fi = self.image_encoder(img), self.imu_encoder(imu)
             return self.pose_net(fv, fi, timestamps, hc)
-        img, imu, ts = self._dev(img, "img"), self._dev(imu, "imu"), self._dev(timestamps, "timestamps")
+        u8 = img.dtype == torch.uint8
+        if u8:
+            # the loader's frames before ToTensor() - 0.5 (reference src/data/KITTI_eval.py:97-110): [B,S,H,W,3] uint8;
+            # the normalisation is fused into the encoder's ingest pass (odevio_forward_u8)
+            if not img.is_cuda:
+                raise RuntimeError("img must be a device tensor (no CPU path)")
+            if img.dim() != 5 or img.shape[-1] != 3 or tuple(img.shape[2:4]) != (self.opt.img_h, self.opt.img_w):
+                raise ValueError(f"uint8 frames must be [B,S,{self.opt.img_h},{self.opt.img_w},3], got {tuple(img.shape)}")
+            img = img.detach().contiguous()
+        else:
+            img = self._dev(img, "img")
+        imu, ts = self._dev(imu, "imu"), self._dev(timestamps, "timestamps")
         B, S = img.shape[0], img.shape[1]
         L, F = self.opt.rnn_num_layers, self.opt.v_f_len + self.opt.i_f_len
         hcp = None
@@ -257,8 +270,9 @@ class DeepVIO(nn.Module):
         poses = torch.empty(B, S - 1, 6, device=img.device, dtype=torch.float32)
         h_T = torch.empty(L, B, F, device=img.device, dtype=torch.float32)
         with torch.cuda.device(img.device):
-            _lib.check(self._lib.odevio_forward(self._plan, img.data_ptr(), imu.data_ptr(), imu.shape[1], ts.data_ptr(),
-                                                hcp, B, S, poses.data_ptr(), h_T.data_ptr(), None, self._stream()))
+            fwd = self._lib.odevio_forward_u8 if u8 else self._lib.odevio_forward
+            _lib.check(fwd(self._plan, img.data_ptr(), imu.data_ptr(), imu.shape[1], ts.data_ptr(),
+                           hcp, B, S, poses.data_ptr(), h_T.data_ptr(), None, self._stream()))
         return poses, h_T
 
     # ------------------------------------------------------------------ component entry points (tests, bench)

@@ -442,3 +442,25 @@ def test_stream_windows_carry_hidden_state(dev, model_type, solver):
     # a drive streamed alone gives the same poses as in the lock-step batch
     alone = tester.test_paths(model, drives[1:2])[0]
     assert_close(torch.from_numpy(alone), torch.from_numpy(est[1]), tol=1e-5, what="lock-step vs alone")
+
+
+def test_forward_from_uint8_frames(dev):
+    """the loader's uint8 HWC frames go in directly; byte / 255 - 0.5 (ToTensor() - 0.5, reference
+    src/data/utils.py:359, KITTI_eval.py:100-103) is fused into the encoder's ingest pass.  Must equal the float path fed
+    with the same normalisation done by torch, and the oracle."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    model, sd = make_model(opt, seed=81)
+    B, S = 3, 4
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (B, S, 64, 128, 3), generator=g, dtype=torch.uint8)
+    _, imu, ts = synth.batch(B, S, 64, 128, drop=0.3, seed=12)
+    as_float = frames.permute(0, 1, 4, 2, 3).float().div(255) - 0.5          # what the reference's loader produces
+    p_u8, h_u8 = model(frames.cuda(), imu.cuda(), ts.cuda())
+    p_f, h_f = model(as_float.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    assert torch.equal(p_u8, p_f) and torch.equal(h_u8, h_f)                 # same fp32 values enter the same kernels
+    ref_p, ref_h = oc.deepvio_forward(sd, as_float, imu, ts, None, opt)
+    assert_close(p_u8, ref_p, what="poses from uint8 frames")
+    assert_close(h_u8, ref_h, what="h_T from uint8 frames")
+    with pytest.raises(ValueError):
+        model(frames[:, :, :32].cuda(), imu.cuda(), ts.cuda())
