@@ -464,3 +464,32 @@ def test_forward_from_uint8_frames(dev):
     assert_close(h_u8, ref_h, what="h_T from uint8 frames")
     with pytest.raises(ValueError):
         model(frames[:, :, :32].cuda(), imu.cuda(), ts.cuda())
+
+
+def test_baseline_config0_single_clip(dev):
+    """BASELINE configs[0]'s shape: one clip, batch 1, seq-len 11, 256x512, RK4 fixed step, fp32."""
+    opt = default_opt(ode_solver="rk4")
+    model, sd = make_model(opt, seed=91, randomize=False)
+    img, imu, ts = synth.batch(1, 11, 256, 512, seed=21)
+    poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    ref_p, ref_h = oc.deepvio_forward(sd, img, imu, ts, None, opt)
+    assert poses.shape == (1, 10, 6)
+    assert_close(poses, ref_p, what="poses")
+    assert_close(h, ref_h, what="h_T")
+
+
+def test_pose_cde_wide_hidden(dev):
+    """Towards BASELINE configs[4] (hidden 1024): the CDE vector field at hidden 512 (its last layer is a
+    [512*513, 512] matrix, 0.54 GB), fixed-grid solver so that the CPU oracle stays within seconds."""
+    opt = default_opt(img_h=64, img_w=128, model_type="cde", cde_hidden_dim=512, v_f_len=384, i_f_len=128,
+                      cde_solver="euler", cde_fn_num_layers=1)
+    model, sd = make_model(opt, seed=63)
+    B = 2
+    g = torch.Generator().manual_seed(7)
+    fv, fi = torch.randn(B, 2, 384, generator=g) * 0.5, torch.randn(B, 2, 128, generator=g) * 0.5
+    ts = synth.timestamps(B, 3, seed=5)
+    poses, z0 = model.pose_cde(fv.cuda(), fi.cuda(), ts.cuda(), None)
+    ref_p, ref_z0, _ = oc.pose_cde(sd, fv, fi, ts, None, None, opt, training=False)
+    assert_close(z0, ref_z0, what="z0")
+    assert_close(poses, ref_p, what="poses")
