@@ -493,3 +493,41 @@ def test_pose_cde_wide_hidden(dev):
     ref_p, ref_z0, _ = oc.pose_cde(sd, fv, fi, ts, None, None, opt, training=False)
     assert_close(z0, ref_z0, what="z0")
     assert_close(poses, ref_p, what="poses")
+
+
+def test_f32_mfma_encoder_mode(dev, monkeypatch):
+    """ODEVIO_CONV_MATH=f32 (read at plan creation) runs the encoder on the fp32-input MFMA kernels; same parity bar."""
+    monkeypatch.setenv("ODEVIO_CONV_MATH", "f32")
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    model, sd = make_model(opt, seed=92)
+    img, imu, ts = synth.batch(2, 4, 64, 128, seed=14)
+    poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    ref_p, ref_h = oc.deepvio_forward(sd, img, imu, ts, None, opt)
+    assert_close(poses, ref_p, what="poses (f32 MFMA encoder)")
+    assert_close(h, ref_h, what="h_T (f32 MFMA encoder)")
+    monkeypatch.setenv("ODEVIO_CONV_MATH", "fp8")
+    from odevio_amd import DeepVIO
+    bad = DeepVIO(opt, seed=1).cuda()
+    with pytest.raises(ValueError):
+        bad(img.cuda(), imu.cuda(), ts.cuda())
+
+
+def test_f16x2_range_guard_is_loud(dev):
+    """An encoder activation beyond the fp16 range cannot be carried as two fp16 pieces: the epilogue raises the
+    status word and check() fails instead of returning inf/nan poses silently."""
+    from odevio_amd._lib import OdevioError
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    model, sd = make_model(opt, seed=93)
+    big = {k: v.clone() for k, v in sd.items()}
+    big["Image_net.conv1.0.weight"] *= 3e6          # conv1 outputs ~1e5
+    model.load_state_dict(big)
+    img, imu, ts = synth.batch(1, 3, 64, 128, seed=15)
+    model(img.cuda(), imu.cuda(), ts.cuda())
+    with pytest.raises(OdevioError, match="fp16x2 range"):
+        model.check()
+    model.load_state_dict(sd)                        # the plan is rebuilt; the flag was cleared by check()
+    poses, _ = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    ref_p, _ = oc.deepvio_forward(sd, img, imu, ts, None, opt)
+    assert_close(poses, ref_p, what="poses after recovery")
