@@ -71,12 +71,22 @@ def conv_roofline(conv_tflops):
         peak, kern, key = F16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT, "conv_f16x2_kernel (conv2..conv6)", "conv_f16x2_kernel"
     return {"kernel": kern, "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(conv_tflops / peak, 4), "traffic": pmc_traffic(key),
+            "pmc": pmc_derived("conv_f16x2") if CONV_MATH != "f32" else None,
             "executed_mfma_tflops": round(conv_tflops * MFMA_PER_PRODUCT, 1),
             "executed_mfma_peak": FP32_MFMA_PEAK_TFLOPS if CONV_MATH == "f32" else F16_MFMA_PEAK_TFLOPS,
             "note": f"fp32 operands as two fp16 pieces (22-bit significands), {MFMA_PER_PRODUCT} fp16 MFMAs per fp32 product, fp32 accumulate; "
                     f"peak = dense fp16 MFMA peak / {MFMA_PER_PRODUCT}; the fp32-input MFMA peak is 157.3; "
                     "traffic = HBM bytes per forward of these launches from profiles/r01_pmc_traffic.json" if CONV_MATH != "f32" else
                     "fp32-input MFMA; traffic = HBM bytes per forward from profiles/r01_pmc_traffic.json"}
+
+
+def pmc_derived(name):
+    """Utilisation figures of a kernel from the committed rocprofv3 PMC passes (tools/pmc_derive.py), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{name}_derived.json")))
+        return {k: d[k] for k in ("clock_ghz", "mfma_busy", "lds_active", "lds_conflict", "ta_busy_avg", "wave_wait") if k in d}
+    except Exception:
+        return None
 
 
 def pmc_traffic(kernel_key):
