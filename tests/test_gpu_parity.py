@@ -43,13 +43,14 @@ def nhwc(x):
 # ------------------------------------------------------------------------------------------------
 # kernel level
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("hw", [(64, 128), (96, 160)])
+@pytest.mark.parametrize("hw", [(64, 128), (96, 160), (80, 208), (256, 512)])
 def test_conv_blocks_one_by_one(dev, hw):
-    """Every conv block alone, fed with the ORACLE's input for that block (errors cannot compound)."""
+    """Every conv block alone, fed with the ORACLE's input for that block (errors cannot compound).  Sizes: multiples
+    of the tile grids, ragged ones (partial 8x32 conv1 tiles, partial 256-pixel GEMM tiles) and the KITTI size."""
     H, W = hw
     opt = default_opt(img_h=H, img_w=W)
     model, sd = make_model(opt, seed=21)
-    B, S = 2, 3
+    B, S = (1, 2) if H == 256 else (2, 3)
     img = synth.images(B, S, H, W, seed=5)
     _, inter = oc.image_encoder(sd, img, return_intermediate=True)
     names = [n for n, _, _ in oc.IMAGE_CONVS]
