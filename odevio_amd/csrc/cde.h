@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define CDE_BT 8          // batch rows per pass of cde_last_kernel
+#define CDE_BT 16         // batch rows per pass of cde_last_kernel (the N of its 16x16x4 MFMA)
 #define CDE_MAX_LIN 6
 
 struct CdeCoefs { float c[8]; };

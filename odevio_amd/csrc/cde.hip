@@ -55,51 +55,59 @@ __global__ void cde_control_grad_kernel(const float* __restrict__ obs, float* __
 }
 
 // out[b][h] = sum_c tanh(sum_k W[h*C + c][k] x[b][k] + bias[h*C + c]) * g[b][c]
-// One workgroup per h; thread t owns columns c = t, t+256, ...; x for a chunk of CDE_BT batch rows sits in LDS.
+// One workgroup per h streams that h's C weight rows (C*H floats, contiguous) ONCE per 16 batch rows - the layer is a
+// pure weight stream (4.3 GB at H = 1024 against 34 GFLOP for B = 16).  The products run on the fp32 MFMA
+// (v_mfma_f32_16x16x4_f32, an exact fmaf chain): a wave takes 16 weight rows (MFMA rows) x 16 batch rows (MFMA
+// columns).  Lane (r = lane&15, q = lane>>4) loads W[row r][16 i + 4 q .. +3] as one float4 - 64 contiguous bytes per
+// row and instruction, eight of them in flight per lane - and feeds element j to MFMA j of the group, whose k-set is
+// {4 q' + j}: any bijection of k works as long as the x fragment (x[b][16 i + 4 q + j], from LDS, row stride H + 8
+// floats = conflict-free b128 reads) uses the same one.  Bias + tanh + the contraction with dX/dt are fused, so the
+// [B, H, C] tensor never exists.
 __global__ __launch_bounds__(256) void cde_last_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                        const float* __restrict__ bias, const float* __restrict__ g,
                                                        float* __restrict__ out, int B, int H, int C) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [CDE_BT][H] then [CDE_BT][4] reduction scratch
-  float* red = xs + CDE_BT * H;
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [CDE_BT][H + 8] then [4 waves][CDE_BT] reduction scratch
+  const int ldx = H + 8;
+  float* red = xs + CDE_BT * ldx;
   const int h = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int nblk = (C + 15) >> 4;
+  const float* Wh = W + (size_t)h * C * H;
+  const float* bh = bias + (size_t)h * C;
   for (int b0 = 0; b0 < B; b0 += CDE_BT) {
     const int nb = min(CDE_BT, B - b0);
     __syncthreads();
-    for (int i = tid; i < nb * H; i += 256) xs[i] = x[(size_t)b0 * H + i];
+    for (int i = tid; i < CDE_BT * H; i += 256) {
+      const int bb = i / H, k = i - bb * H;
+      xs[bb * ldx + k] = bb < nb ? x[(size_t)(b0 + bb) * H + k] : 0.f;
+    }
     __syncthreads();
-    float part[CDE_BT];
+    float part = 0.f;                       // this lane's share of out[b0 + r][h]
+    const float* xrow = xs + r * ldx + 4 * q;
+    for (int blk = wave; blk < nblk; blk += 4) {
+      const int c_ld = min(blk * 16 + r, C - 1);           // rows past C re-read the last row; masked below
+      const float* wrow = Wh + (size_t)c_ld * H + 4 * q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int k = 0; k < H; k += 16) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + k);
 #pragma unroll
-    for (int b = 0; b < CDE_BT; ++b) part[b] = 0.f;
-    for (int c = tid; c < C; c += 256) {
-      const float* w = W + ((size_t)h * C + c) * H;
-      float acc[CDE_BT];
-#pragma unroll
-      for (int b = 0; b < CDE_BT; ++b) acc[b] = 0.f;
-      for (int k = 0; k < H; k += 4) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
-#pragma unroll
-        for (int b = 0; b < CDE_BT; ++b) {
-          if (b < nb) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + b * H + k);
-            acc[b] = fmaf(wv[0], xv[0], fmaf(wv[1], xv[1], fmaf(wv[2], xv[2], fmaf(wv[3], xv[3], acc[b]))));
-          }
-        }
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[j], acc, 0, 0, 0);
       }
-      const float bi = bias[(size_t)h * C + c];
+      // D: column (= batch row) = lane&15, row (= weight row inside the block) = 4*(lane>>4) + reg
 #pragma unroll
-      for (int b = 0; b < CDE_BT; ++b)
-        if (b < nb) part[b] = fmaf(tanhf(acc[b] + bi), g[(size_t)(b0 + b) * C + c], part[b]);
+      for (int e = 0; e < 4; ++e) {
+        const int c = blk * 16 + 4 * q + e;
+        if (c < C && r < nb) part = fmaf(tanhf(acc[e] + bh[c]), g[(size_t)(b0 + r) * C + c], part);
+      }
     }
-#pragma unroll
-    for (int b = 0; b < CDE_BT; ++b) {
-      float s = part[b];
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-      if (lane == 0) red[b * 4 + wave] = s;
-    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (lane < 16) red[wave * CDE_BT + lane] = part;
     __syncthreads();
-    if (tid < nb) out[(size_t)(b0 + tid) * H + h] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
+    if (tid < nb) out[(size_t)(b0 + tid) * H + h] = (red[tid] + red[CDE_BT + tid]) + (red[2 * CDE_BT + tid] + red[3 * CDE_BT + tid]);
   }
 }
 
@@ -189,7 +197,7 @@ void cde_launch_control_grad(const float* obs, float* g, int B, int L, int C, in
   hipLaunchKernelGGL(cde_control_grad_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, obs, g, B, L, C, seg);
 }
 void cde_launch_last(const float* x, const float* W, const float* bias, const float* g, float* out, int B, int H, int C, hipStream_t st) {
-  const size_t lds = ((size_t)CDE_BT * H + CDE_BT * 4) * sizeof(float);
+  const size_t lds = ((size_t)CDE_BT * (H + 8) + CDE_BT * 4) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cde_last_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
