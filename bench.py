@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # not part of the driver's contract: other BASELINE configurations on the same harness (configs[2]: dopri5, 50 % drop)
+    ap.add_argument("--ode-solver", default="rk4")
+    ap.add_argument("--drop", type=float, default=0.0, help="frame-drop probability of the synthetic timestamps")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,11 +168,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     from odevio_amd import DeepVIO
-    opt = default_opt(ode_solver="rk4")
+    opt = default_opt(ode_solver=args.ode_solver)
     model = DeepVIO(opt, seed=0)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.cuda()
-    img, imu, ts = synth.batch(B, S, H, W, seed=100 + rank)
+    img, imu, ts = synth.batch(B, S, H, W, drop=args.drop, seed=100 + rank)
     img, imu, ts = img.cuda(), imu.cuda(), ts.cuda()
     gathered = torch.empty(world * B, S - 1, 6, device="cuda") if world > 1 else None
 
@@ -222,10 +225,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 in, fp32 out, fp32 accumulate everywhere; conv2..conv6 products via " + CONV_MATH + (" operand split: operands to 2^-22, products exact, see DESIGN.md section 4" if CONV_MATH != "f32" else " MFMA"),
             "config": {"workload": f"DeepVIO.forward: {B} sequences x {S} frames 256x512 per GPU, ODEFunc 768-512-512-512-768, "
-                                   f"RK4 (3/8) 1 step/interval, 2-layer tanh RNN, fp32 (BASELINE configs[1])",
-                       "sequences_per_gpu": B, "seq_len": S, "ode_solver": "rk4", "sharding": f"sequences x{world}"},
-            "integrator": {"steps_per_s": round(n_rk4 / integ_s, 1), "rows": rows, "unit": "RK4 steps/s of the [32,768] state, inside the ODE-RNN loop (RNN cell included)",
-                           "ms_per_forward": round(stage_ms["integrator"], 4)},
+                                   f"RK4 (3/8) 1 step/interval, 2-layer tanh RNN, fp32 (BASELINE configs[1])" if (args.ode_solver, args.drop) == ("rk4", 0.0)
+                                   else f"{args.ode_solver}, timestamp drop {args.drop}, 2-layer tanh RNN, fp32",
+                       "sequences_per_gpu": B, "seq_len": S, "ode_solver": args.ode_solver, "sharding": f"sequences x{world}"},
+            "integrator": ({"steps_per_s": round(n_rk4 / integ_s, 1), "rows": rows, "unit": "RK4 steps/s of the [32,768] state, inside the ODE-RNN loop (RNN cell included)",
+                            "ms_per_forward": round(stage_ms["integrator"], 4)} if args.ode_solver in ("rk4", "rk4_classic") else
+                           {"intervals_per_s": round((S - 1) / integ_s, 1), "rows": rows, "unit": f"frame intervals/s of the [32,768] state ({args.ode_solver}, adaptive steps), RNN cell included",
+                            "ms_per_forward": round(stage_ms["integrator"], 4)}),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": conv_roofline(conv_tflops),
             "roofline_integrator": {"kernel": "integrator_kernel", "bound": "hbm",
