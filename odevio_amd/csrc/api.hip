@@ -55,7 +55,10 @@ struct odevio_plan {
   void* conv_ws[9] = {};   // conv2..conv6 weights as two fp16 pieces (conv_f16x2.hip), [Cout][K-tile][2][32], pre-scaled
   float* conv_scale_h[9] = {};  // BatchNorm scale with the weights' power-of-two pre-scale folded back in
   int conv_math = 1;       // 1: fp16x2 operand split on the fp16 MFMA (default); 0: fp32-input MFMA (ODEVIO_CONV_MATH=f32)
-  DevBuf pack_tmp, ingest;
+  DevBuf pack_tmp, ingest, partial_side;
+  // the inertial encoder runs beside the image encoder on its own stream (odevio_forward)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* zero_page = nullptr;  // what the split kernel's LDS-DMA reads for taps outside the image
   float* conv_scale[9] = {};
   float* conv_shift[9] = {};
@@ -208,9 +211,12 @@ extern "C" const char* odevio_last_error(void) { return g_err; }
 
 extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (!p) return;
+  if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->hT_scratch, &p->cde_ws, &p->pack_tmp, &p->ingest})
+                    &p->hT_scratch, &p->cde_ws, &p->pack_tmp, &p->ingest, &p->partial_side})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
@@ -529,7 +535,8 @@ static int pick_splitk(int M, int N, int nk) {
 
 static int run_gemm(odevio_plan* p, const float* in, int M, int K, const float* W, int N, const float* scale,
                     const float* shift, const float* mul, int ld_mul, float* out, int ld_out, int act, float slope,
-                    hipStream_t st) {
+                    hipStream_t st, DevBuf* slabs = nullptr) {
+  if (!slabs) slabs = &p->partial;   // split-K slabs; work that runs on the side stream brings its own
   ConvArgs a{};
   a.in = in; a.w = W; a.scale = scale; a.shift = shift; a.mul = mul; a.out = out;
   a.N = M; a.Hi = a.Wi = a.Ho = a.Wo = 1; a.Cin = K; a.Cout = N; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
@@ -539,9 +546,9 @@ static int run_gemm(odevio_plan* p, const float* in, int M, int K, const float* 
   a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
   a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
   if (a.splitk > 1) {
-    int rc = ensure(p->partial, (size_t)a.splitk * M * N);
+    int rc = ensure(*slabs, (size_t)a.splitk * M * N);
     if (rc) return rc;
-    a.partial = p->partial.p;
+    a.partial = slabs->p;
   }
   launch_conv_igemm(a, st);
   return 0;
@@ -669,7 +676,8 @@ static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* f
   return rc;
 }
 
-static int imu_encoder(odevio_plan* p, const float* imu, int B, int T, float* fi, int ld_fi, hipStream_t st) {
+static int imu_encoder(odevio_plan* p, const float* imu, int B, int T, float* fi, int ld_fi, hipStream_t st,
+                       DevBuf* slabs = nullptr) {
   const int pps = (T - 1) / 10;
   const int P = B * pps;
   int rc;
@@ -680,7 +688,7 @@ static int imu_encoder(odevio_plan* p, const float* imu, int B, int T, float* fi
   a.out = p->imu_act.p; a.B = B; a.T = T; a.pairs_per_seq = pps;
   launch_imu_convs(a, st);
   return run_gemm(p, p->imu_act.p, P, 2816, p->proj_w, p->cfg.i_f_len, nullptr, p->proj_b, nullptr, 0, fi, ld_fi,
-                  EPI_NONE, 0.f, st);
+                  EPI_NONE, 0.f, st, slabs);
 }
 
 __global__ void concat_kernel(const float* fv, int nv, const float* fi, int ni, float* out, int P) {
@@ -1063,9 +1071,21 @@ static int forward_any(odevio_plan* p, const void* img, bool img_u8, const float
   const int P = B * (S - 1), F = p->F;
   int rc;
   if ((rc = ensure(p->fcat, (size_t)P * F)) || (rc = ensure(p->fused, (size_t)P * F))) return rc;
-  // encoders write straight into the concatenated feature rows (torch.cat of FusionModule.py:19 is free)
+  // encoders write straight into the concatenated feature rows (torch.cat of FusionModule.py:19 is free).  The
+  // inertial encoder (latency-bound: 160 small workgroups + one skinny GEMM) runs on the plan's side stream underneath
+  // the image encoder; both join before the fusion.  Allocations first: nothing may (re)allocate while two streams run.
+  if ((rc = ensure(p->imu_act, (size_t)P * 2816)) || (rc = ensure(p->partial_side, (size_t)64 * P * p->cfg.i_f_len))) return rc;
+  if (!p->side) {
+    HIPCHK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(p->ev_fork, st));
+  HIPCHK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+  if ((rc = imu_encoder(p, imu, B, T, p->fcat.p + p->cfg.v_f_len, F, p->side, &p->partial_side))) return rc;
+  HIPCHK(hipEventRecord(p->ev_join, p->side));
   if ((rc = image_encoder(p, img, B, S, p->fcat.p, F, st, img_u8))) return rc;
-  if ((rc = imu_encoder(p, imu, B, T, p->fcat.p + p->cfg.v_f_len, F, st))) return rc;
+  HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
   const float* fused = p->fcat.p;
   if (p->cfg.fuse_method != ODEVIO_FUSE_CAT) {
     if ((rc = fuse_from_cat(p, p->fcat.p, P, p->fused.p, st))) return rc;
