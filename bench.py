@@ -101,6 +101,39 @@ def pmc_traffic(kernel_key):
         return None
 
 
+def f32_reference(opt, sd, img, imu, ts, steps=5):
+    """The same forward with the encoder on the fp32-input MFMA kernels (ODEVIO_CONV_MATH=f32, read at plan creation):
+    reported beside the headline so that the effect of the fp16x2 operand split is visible in one line."""
+    from odevio_amd import DeepVIO
+    old = os.environ.get("ODEVIO_CONV_MATH")
+    os.environ["ODEVIO_CONV_MATH"] = "f32"
+    try:
+        m = DeepVIO(opt, seed=0)
+        m.load_state_dict(sd)
+        m = m.cuda()
+        for _ in range(2):
+            m(img, imu, ts)
+        m.check()
+        m.profile_enable(True)
+        conv_ms = 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(img, imu, ts)
+            conv_ms += m.profile_read()["conv2_6"]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        if old is None:
+            del os.environ["ODEVIO_CONV_MATH"]
+        else:
+            os.environ["ODEVIO_CONV_MATH"] = old
+    tf = conv_flops_per_pair() * B * (S - 1) / (conv_ms / steps * 1e-3) / 1e12
+    return {"value": round(B * S / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "conv2_6_tflops": round(tf, 1), "conv2_6_frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 3),
+            "note": "ODEVIO_CONV_MATH=f32: conv1..conv6 on v_mfma_f32_32x32x2_f32, everything else identical"}
+
+
 def cpu_baseline(opt, sd, budget_s=20.0):
     from oracle import odevio_oracle as oc  # the oracle is the CPU baseline leg, nothing else
     nb = 1
@@ -148,6 +181,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-reference", action="store_true", help="skip the short run with the fp32-input MFMA encoder")
     # not part of the driver's contract: other BASELINE configurations on the same harness (configs[2]: dopri5, 50 % drop)
     ap.add_argument("--ode-solver", default="rk4")
     ap.add_argument("--drop", type=float, default=0.0, help="frame-drop probability of the synthetic timestamps")
@@ -239,6 +273,8 @@ def main():
                                     "frac": round(integ_bytes / integ_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("integrator_kernel<4>"),
                                     "note": "latency-bound by design: weights stay in LDS, algorithmic bytes assume a re-read per stage"},
         }
+        if world == 1 and CONV_MATH != "f32" and not args.no_f32_reference:
+            out["fp32_mfma_encoder"] = f32_reference(opt, sd, img, imu, ts)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt, sd)
         print(json.dumps(out), flush=True)
