@@ -1,4 +1,5 @@
 // Probe: does v_mfma_f32_32x32x16_f16 honour fp16 subnormal inputs?  (decides whether the fp16x2 operand split is usable)
+// Build: hipcc -O2 --offload-arch=gfx950 f16_denorm_mfma.hip -o f16_denorm_mfma   (result on MI355X: subnormal inputs are honoured, every case exact)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
