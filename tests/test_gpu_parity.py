@@ -532,3 +532,19 @@ def test_f16x2_range_guard_is_loud(dev):
     model.check()
     ref_p, _ = oc.deepvio_forward(sd, img, imu, ts, None, opt)
     assert_close(poses, ref_p, what="poses after recovery")
+
+
+def test_baseline_config1_full_batch(dev):
+    """BASELINE configs[1] at its real size (16 sequences x 11 frames of 256x512, RK4): the layer shapes, tile counts
+    and split-K factors of the bench.  The oracle checks sequences 0 and 15 (sequences are independent end to end)."""
+    opt = default_opt(ode_solver="rk4")
+    model, sd = make_model(opt, seed=94, randomize=False)
+    img, imu, ts = synth.batch(16, 11, 256, 512, drop=0.2, seed=31)
+    poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    assert poses.shape == (16, 10, 6) and h.shape == (2, 16, 768)
+    assert torch.isfinite(poses).all()
+    for b in (0, 15):
+        ref_p, ref_h = oc.deepvio_forward(sd, img[b:b + 1], imu[b:b + 1], ts[b:b + 1], None, opt)
+        assert_close(poses[b:b + 1], ref_p, what=f"poses of sequence {b}")
+        assert_close(h[:, b:b + 1], ref_h, what=f"h_T of sequence {b}")
