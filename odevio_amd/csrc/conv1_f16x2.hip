@@ -59,24 +59,44 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
     const int y = yp - 3, x0 = 8 * k - 3;
     const bool oky = (unsigned)y < (unsigned)a.H;
     f16x8 h, l;
+    float v8[8];
+    if (!a.src_u8 && (a.W & 3) == 0) {
+      // fp32 frames: the 8 pixels x0 .. x0+7 (x0 = 8k - 3) lie inside the three aligned float4s starting at 8k - 4;
+      // W % 4 == 0 makes each float4 entirely inside or entirely outside the row
+      const float* row = reinterpret_cast<const float*>(a.src) + (plane * a.H + (oky ? y : 0)) * (size_t)a.W;
+      float w12[12];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int xq = 8 * k - 4 + 4 * q;
+        const bool ok = oky && (unsigned)xq < (unsigned)a.W;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(row + (ok ? xq : 0));   // unconditional load, clamped address
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w12[4 * q + e] = ok ? t[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = w12[e + 1];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int x = x0 + e;
+        const bool ok = oky && (unsigned)x < (unsigned)a.W;
+        if (a.src_u8) {
+          const size_t frame = plane / 3;
+          const int c = (int)(plane - frame * 3);
+          const unsigned char* sp = reinterpret_cast<const unsigned char*>(a.src);
+          const unsigned char b = sp[ok ? ((frame * a.H + y) * a.W + x) * 3 + c : 0];
+          v8[e] = ok ? (float)b / 255.0f - 0.5f : 0.f;
+        } else {
+          const float* sp = reinterpret_cast<const float*>(a.src);
+          const float f = sp[ok ? (plane * a.H + y) * a.W + x : 0];
+          v8[e] = ok ? f : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int x = x0 + e;
-      const bool ok = oky && (unsigned)x < (unsigned)a.W;
-      float v = 0.f;
-      if (a.src_u8) {
-        const size_t frame = plane / 3;
-        const int c = (int)(plane - frame * 3);
-        const unsigned char* sp = reinterpret_cast<const unsigned char*>(a.src);
-        const unsigned char b = sp[ok ? ((frame * a.H + y) * a.W + x) * 3 + c : 0];
-        v = ok ? (float)b / 255.0f - 0.5f : 0.f;
-      } else {
-        const float* sp = reinterpret_cast<const float*>(a.src);
-        const float f = sp[ok ? (plane * a.H + y) * a.W + x : 0];
-        v = ok ? f : 0.f;
-      }
-      h[e] = (_Float16)v;
-      l[e] = (_Float16)(v - (float)h[e]);
+      h[e] = (_Float16)v8[e];
+      l[e] = (_Float16)(v8[e] - (float)h[e]);
     }
     _Float16* dst = reinterpret_cast<_Float16*>(a.planes) + ((plane * 2) * a.Hp + yp) * (size_t)a.Wp + 8 * k;
     *reinterpret_cast<f16x8*>(dst) = h;
