@@ -140,7 +140,9 @@ __device__ __forceinline__ void gather(Ctx& c, const u64* buf, unsigned tag, int
             break;
           }
         }
+#ifndef EXP_NOSLEEP
         __builtin_amdgcn_s_sleep(1);
+#endif
       }
     }
   }
