@@ -17,7 +17,7 @@
  *
  * Threading: a plan is not re-entrant (one forward at a time per plan); different plans are
  * independent.  No internal threads.  Nothing synchronises the stream except odevio_plan_create
- * (weight re-layout), odevio_reserve and odevio_check.
+ * (weight re-layout), odevio_reserve, odevio_check and odevio_cde_fwd (host-driven solver).
  */
 #ifndef ODEVIO_H
 #define ODEVIO_H
@@ -90,15 +90,18 @@ int odevio_version(void);
 const char* odevio_last_error(void);
 
 /* Builds a plan: validates the config, finds every weight by name, folds BatchNorm running stats
- * into per-channel (scale, shift), re-lays convolution weights as [Cout][kh][kw][Cin], permutes the
- * visual head to the NHWC flatten order and column-shards the ODEFunc/RNN weights for the
- * persistent integrator.  Replaces: DeepVIO.__init__ + load_state_dict (DeepVIO.py:37-43). */
+ * into per-channel (scale, shift), re-lays the convolution weights (two fp16 pieces per fp32 weight in the K-tile
+ * order of the fp16-MFMA kernels, pre-scaled by a power of two per layer; plus [Cout][kh][kw][Cin] fp32 for the
+ * ODEVIO_CONV_MATH=f32 mode), permutes the visual head to the NHWC flatten order and column-shards the ODEFunc/RNN
+ * weights for the persistent integrator.  Replaces: DeepVIO.__init__ + load_state_dict (DeepVIO.py:37-43).
+ * Environment (diagnostic): ODEVIO_CONV_MATH = f16x2 (default) | f32, read here. */
 int odevio_plan_create(const odevio_config* cfg, const odevio_tensor* weights, int32_t n_weights, void* stream,
                        odevio_plan** out_plan);
 void odevio_plan_destroy(odevio_plan* plan);
 /* Pre-allocates the activation workspace for batches up to (B, S) so that later calls allocate nothing. */
 int odevio_reserve(odevio_plan* plan, int32_t B, int32_t S, void* stream);
-/* Synchronises `stream` and returns the device status word of the last integrator launch. */
+/* Synchronises `stream` and returns the device status words: an integrator timeout / step-budget overflow, or an
+ * encoder activation outside the fp16x2 range (ODEVIO_ERR_RANGE).  Clears what it reports. */
 int odevio_check(odevio_plan* plan, void* stream);
 
 /* ImageEncoder.forward (Encoder.py:97-122): img [B,S,3,H,W] -> fv [B,S-1,v_f_len] with row stride ld_fv. */
@@ -131,7 +134,8 @@ int odevio_ode_rnn_fwd(odevio_plan* plan, const float* fused, const float* ts, c
 int odevio_cde_fwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, const double* t_out_host, int32_t n_out,
                    const float* z0_in, float* poses, float* z0_out, int32_t* stats_host, void* stream);
 /* DeepVIO.forward (DeepVIO.py:61-68): img [B,S,3,H,W], imu [B,T,6], ts [B,S], hc NULL or [L,B,F]
- * -> poses [B,S-1,6], h_T [L,B,F]. */
+ * -> poses [B,S-1,6], h_T [L,B,F].  Asynchronous on `stream`; the inertial encoder runs on a stream owned by the plan,
+ * forked from and joined back into `stream` with events (nothing for the caller to do). */
 int odevio_forward(odevio_plan* plan, const float* img, const float* imu, int32_t T, const float* ts,
                    const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream);
 
