@@ -937,6 +937,11 @@ extern "C" int odevio_check(odevio_plan* p, void* stream) {
     return fail(ODEVIO_ERR_RANGE, "image encoder: an activation left the fp16x2 range (|x| > 65504 or not finite); "
                                   "set ODEVIO_CONV_MATH=f32 for the fp32-input MFMA path");
   }
+  if (hw[ODEVIO_STATUS_RANGE + 1] != 0) {
+    HIPCHK(hipMemsetAsync(p->status + ODEVIO_STATUS_RANGE + 1, 0, sizeof(int), st));
+    HIPCHK(hipStreamSynchronize(st));
+    return fail(ODEVIO_ERR_TIMEOUT, "conv1: a bounded in-kernel group barrier gave up");
+  }
   const int h = hw[0];
   if (h != 0) {
     HIPCHK(hipMemsetAsync(p->status, 0, sizeof(int), st));

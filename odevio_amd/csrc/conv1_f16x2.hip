@@ -331,15 +331,206 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two tiles in flight per CU.  The kernel above owns the CU's LDS with ONE 4-wave workgroup, i.e. one wave per SIMD:
+// nothing hides the dependent-latency chains of its epilogue (~600 instructions per tile) or the LDS latency of the
+// fragment reads.  Here a 512-thread workgroup holds the same filter bank once and runs two independent 4-wave GROUPS,
+// each walking its own tiles with its own (single) patch buffer: load patch -> k-loop -> epilogue, unsynchronised
+// with the other group, so every SIMD has two waves in different phases.  Groups synchronise internally with a
+// monotonic LDS counter (s_barrier would couple the groups); every spin is bounded.
+// P2 output only (the fp32-output form of the API uses the kernel above).
+// ------------------------------------------------------------------------------------------------------------------
+#define H1G_SCALE_BYTES 512
+#define H1G_LDS (H1_W_BYTES + 2 * H1_PATCH_BYTES + H1G_SCALE_BYTES + 64)
+
+__device__ __forceinline__ bool group_barrier(unsigned* ctr, unsigned& target, int lane) {
+  target += 4;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  unsigned spins = 0;
+  while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 24)) return false;   // ~seconds: never in a healthy run; keeps a broken one from hanging
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+
+__global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ws = smem;                                   // [2][42][64][8] fp16
+  float* sc_s = reinterpret_cast<float*>(smem + H1_W_BYTES + 2 * H1_PATCH_BYTES);   // scale[64], shift[64]
+  unsigned* ctrs = reinterpret_cast<unsigned*>(smem + H1_W_BYTES + 2 * H1_PATCH_BYTES + H1G_SCALE_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int grp = tid >> 8;              // 0 / 1
+  const int wave = (tid >> 6) & 3;       // wave inside the group
+  const int fi = lane & 31, fh = lane >> 5;
+  unsigned char* Pg = smem + H1_W_BYTES + grp * H1_PATCH_BYTES;   // this group's patch buffer
+  unsigned* ctr = ctrs + 8 * grp;
+
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.wt16);
+    u32x4* dst = reinterpret_cast<u32x4*>(Ws);
+    for (int i = tid; i < H1_W_BYTES / 16; i += 512) dst[i] = src[i];
+    if (tid < 64) sc_s[tid] = a.scale[tid];
+    else if (tid < 128) sc_s[tid] = a.shift[tid - 64];
+    if (tid < 16) ctrs[tid] = 0u;
+  }
+  __syncthreads();
+
+  const int tiles_per_pair = a.tiles_y * a.tiles_x;
+  const size_t plane_bytes = (size_t)a.Hp * a.Wp * 2;
+  const unsigned char* planes_b = reinterpret_cast<const unsigned char*>(a.planes);
+  int d_off[H1_DMA_PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < H1_DMA_PER_WAVE; ++k) {
+    const int g = H1_DMA_PER_WAVE * wave + k, p = g / 18, q = g - 18 * p;
+    const int r = 7 * q + (lane == 63 ? 7 : lane / 9), pc = lane == 63 ? 0 : lane % 9;
+    const int c = r / H1_PH, y = r - c * H1_PH;
+    d_off[k] = r < H1_ROWS ? (int)((c * 2 + p) * plane_bytes) + y * a.Wp * 2 + pc * 16 : -1;
+  }
+  const int x_lane = ((4 * wave) * H1_PW + 2 * fi) * 2;
+  const int w_lane = (fh * 64 + fi) * 16;
+  unsigned target = 0;
+  bool healthy = true;
+  bool range_bad = false;
+  // (A deliberate half-tile phase offset between the groups was measured 4 % slower than letting them drift.)
+
+  for (int tile = blockIdx.x * 2 + grp; tile < a.n_tiles && healthy; tile += gridDim.x * 2) {
+    const int pair = tile / tiles_per_pair;
+    const int t = tile - pair * tiles_per_pair;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    {
+      const int b = pair / (a.S - 1), fr = pair - b * (a.S - 1);
+      const unsigned char* corner =
+          planes_b + ((size_t)b * a.S + fr) * 6 * plane_bytes + ((size_t)(2 * ty * H1_TH) * a.Wp + 2 * tx * H1_TW) * 2;
+#pragma unroll
+      for (int k = 0; k < H1_DMA_PER_WAVE; ++k) {
+        const int g = H1_DMA_PER_WAVE * wave + k, p = g / 18, q = g - 18 * p;
+        const unsigned char* src = d_off[k] >= 0 ? corner + d_off[k] : reinterpret_cast<const unsigned char*>(a.zeros);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Pg + p * H1_PIECE_BYTES + 7 * q * H1_PW * 2), 16, 0, 0);
+      }
+    }
+    healthy = group_barrier(ctr, target, lane);   // own DMAs landed (vmcnt(0) inside) -> the group's patch is complete
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f16x8 xf[2][2][2], wf[2][2][2];
+    auto krow_off = [](int kr) { return ((kr / 7) * H1_PH + (kr % 7)) * H1_PW * 2; };
+    auto read_frags = [&](int set, int s) __attribute__((always_inline)) {
+      const int xo = x_lane + (fh ? krow_off(2 * s + 1) : krow_off(2 * s));
+      const int wo = w_lane + 2 * s * 64 * 16;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned char* px = Pg + p * H1_PIECE_BYTES + xo + i * 2 * H1_PW * 2;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(px);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(px + 8);
+          u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+          xf[set][i][p] = __builtin_bit_cast(f16x8, v);
+          wf[set][i][p] = *reinterpret_cast<const f16x8*>(Ws + p * H1_WPIECE_BYTES + wo + i * 32 * 16);
+        }
+      }
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < 21; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < 21) read_frags(cur ^ 1, s + 1);
+      constexpr int PW[3] = {1, 0, 0};
+      constexpr int PX[3] = {0, 1, 0};
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][0][PW[tt]], xf[cur][0][PX[tt]], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][1][PW[tt]], xf[cur][0][PX[tt]], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][0][PW[tt]], xf[cur][1][PX[tt]], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][1][PW[tt]], xf[cur][1][PX[tt]], acc[1][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    healthy = healthy && group_barrier(ctr, target, lane);   // every wave of the group is done reading the patch
+
+    // epilogue through this group's patch buffer (see the kernel above), BN constants from LDS
+    {
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      unsigned char* stg = Pg + wave * (H1_PATCH_BYTES / 4);
+      unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int oy = ty * H1_TH + 2 * wave + mt;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = nt * 32 + 8 * g + 4 * fh;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sc_s + n);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(sc_s + 64 + n);
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
+              x = fmaxf(x, x * a.slope);
+              range_bad |= !(fabsf(x) <= 65504.f);
+              h[e] = (_Float16)x;
+              l[e] = (_Float16)(x - (float)h[e]);
+            }
+            unsigned char* q = stg + fi * 264 + nt * 128 + (8 * g + 4 * fh) * 2;
+            *reinterpret_cast<f16x4*>(q) = h;
+            *reinterpret_cast<f16x4*>(q + 64) = l;
+          }
+        }
+        if (oy < a.Ho) {
+          const size_t opix0 = ((size_t)pair * a.Ho + oy) * a.Wo + tx * H1_TW;
+          const int px_valid = min(H1_TW, a.Wo - tx * H1_TW);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int o = (it * 64 + lane) * 16;
+            const int px = o >> 8, within = o & 255;
+            const unsigned char* q = stg + px * 264 + within;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(q);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(q + 8);
+            if (px < px_valid) {
+              u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+              *reinterpret_cast<u32x4*>(outb + opix0 * 256 + o) = v;
+            }
+          }
+        }
+      }
+    }
+    // the staging area is the patch buffer the next iteration's DMAs refill: every wave's staging reads must be done
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    healthy = healthy && group_barrier(ctr, target, lane);
+  }
+  if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
+  if (!healthy) a.status[ODEVIO_STATUS_RANGE + 1] = 1;
+}
+
 hipError_t launch_conv1_f16x2(const Conv1Args& a, int n_cu, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H1_LDS);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
+    if (e != hipSuccess) return e;
     attr_set = true;
   }
   (void)hipGetLastError();
-  const int grid = n_cu < a.n_tiles ? n_cu : a.n_tiles;
-  hipLaunchKernelGGL(conv1_f16x2_kernel, dim3(grid), dim3(256), H1_LDS, st, a);
+  static const bool single = getenv("ODEVIO_CONV1_SINGLE") != nullptr;   // diagnostic: the one-group kernel
+  if (a.out_split && !single) {
+    const int pairs_of_tiles = (a.n_tiles + 1) / 2;
+    const int grid = n_cu < pairs_of_tiles ? n_cu : pairs_of_tiles;
+    hipLaunchKernelGGL(conv1_f16x2_g2_kernel, dim3(grid), dim3(512), H1G_LDS, st, a);
+  } else {
+    const int grid = n_cu < a.n_tiles ? n_cu : a.n_tiles;
+    hipLaunchKernelGGL(conv1_f16x2_kernel, dim3(grid), dim3(256), H1_LDS, st, a);
+  }
   return hipGetLastError();
 }
