@@ -64,6 +64,8 @@ struct odevio_plan {
   float* conv_shift[9] = {};
   int conv_h[10] = {}, conv_w_sp[10] = {};  // spatial size before conv i (index 0 = image)
   float *head_w = nullptr, *head_b = nullptr;
+  void* head_ws = nullptr;       // visual head as a 1x1 convolution for the fp16x2 kernel: [v_f_len][K/32][2][32] fp16
+  float* head_scale_h = nullptr; // 1 / prescale per output
   int head_k = 0;
   float *imu_w[3] = {}, *imu_s[3] = {}, *imu_h[3] = {};
   float *proj_w = nullptr, *proj_b = nullptr;
@@ -377,6 +379,15 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
         for (int s = 0; s < oh * ow; ++s)
           t[(size_t)n * p->head_k + (size_t)s * 1024 + c] = w[(size_t)n * p->head_k + (size_t)c * oh * ow + s];
     TRY(upload(p, &p->head_w, t, st));
+    {  // the same matrix as two fp16 pieces (K = (H,W,C) order = the P2 layout of conv6's output, one 'pixel' per pair)
+      std::vector<uint16_t> ws;
+      const float prescale = split_conv_weights(t, cfg->v_f_len, p->head_k, 1, ws);
+      TRY(dev_alloc(p, &p->head_ws, ws.size() * sizeof(uint16_t)));
+      HIPCHK(hipMemcpyAsync(p->head_ws, ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+      std::vector<float> hs((size_t)cfg->v_f_len, 1.0f / prescale);
+      TRY(upload(p, &p->head_scale_h, hs, st));
+    }
     TRY(wt.get("Image_net.visual_head.bias", cfg->v_f_len, bias));
     TRY(upload(p, &p->head_b, bias, st));
   }
@@ -561,7 +572,7 @@ static int pick_splitk_h(int M, int N, int nk) {
   if (tiles >= 1024 || nk < 24) return 1;
   int best = 1;
   double best_cost = 1e30;
-  for (int s : {1, 2, 3, 4, 6, 8, 12}) {
+  for (int s : {1, 2, 3, 4, 6, 8, 12, 16, 32, 64}) {
     if (s > 1 && nk / s < 12) break;
     const double rounds = std::ceil(tiles * s / 256.0);
     const double steps = std::ceil((double)nk / s) + 6.0;
@@ -611,7 +622,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.in = in; a.w = p->conv_ws[i]; a.zeros = p->zero_page; a.scale = p->conv_scale_h[i]; a.shift = p->conv_shift[i]; a.out = out; a.status = p->status;
     a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
     a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
-    a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split;
+    a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.ld_out = cs.cout;
     const int nk = cs.k * cs.k * cs.cin / 32;
     a.splitk = pick_splitk_h(a.M, a.Cout, nk);
     a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
@@ -667,11 +678,31 @@ static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* f
   float* cur = p->actA.p;
   for (int i = 1; i < 9; ++i) {
     float* nxt = (cur == p->actA.p) ? p->actB.p : p->actA.p;
-    if ((rc = conv_block(p, i, cur, B, S, nxt, split, split && i < 8, st))) return rc;
+    if ((rc = conv_block(p, i, cur, B, S, nxt, split, split, st))) return rc;
     cur = nxt;
   }
   stage_mark(p, 2, st);
-  rc = run_gemm(p, cur, P, p->head_k, p->head_w, p->cfg.v_f_len, nullptr, p->head_b, nullptr, 0, fv, ld_fv, EPI_NONE, 0.f, st);
+  if (split) {
+    // visual head = a 1x1 convolution over conv6's P2 output seen as P 'pixels' of head_k channels: the 67 MB weight
+    // stream split 64 ways over K so that every CU takes part
+    ConvSplitArgs a{};
+    a.in = cur; a.w = p->head_ws; a.zeros = p->zero_page; a.scale = p->head_scale_h; a.shift = p->head_b; a.out = fv;
+    a.status = p->status;
+    a.N = P; a.Hi = a.Wi = a.Ho = a.Wo = 1; a.Cin = p->head_k; a.Cout = p->cfg.v_f_len; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
+    a.M = P; a.slope = 1.0f; a.out_split = 0; a.ld_out = ld_fv;
+    const int nk = p->head_k / 32;
+    a.splitk = pick_splitk_h(a.M, a.Cout, nk);
+    a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
+    a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
+    if (a.splitk > 1) {
+      if ((rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout))) return rc;
+      a.partial = p->partial.p;
+    }
+    HIPCHK(launch_conv_f16x2(a, st));
+    rc = 0;
+  } else {
+    rc = run_gemm(p, cur, P, p->head_k, p->head_w, p->cfg.v_f_len, nullptr, p->head_b, nullptr, 0, fv, ld_fv, EPI_NONE, 0.f, st);
+  }
   stage_mark(p, 3, st);
   return rc;
 }

@@ -45,6 +45,7 @@ struct ConvSplitArgs {
   int M;
   float slope;          // LeakyReLU slope (the only epilogue the encoder needs)
   int out_split;
+  int ld_out;           // row stride (floats) of an fp32 output (out_split = 0)
   int splitk, ktiles_per_split;
   int xcd_map;
 };

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           v[e] = x > 0.f ? x : x * a.slope;
         }
         if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
-        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.Cout + n) = v;
+        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ld_out + n) = v;
       }
     }
   }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16x2_kernel(ConvSplitArgs 
       v[e] = x > 0.f ? x : x * a.slope;
     }
     if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), m, n, a.Cout, v);
-    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + e0) = v;
+    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + m * (size_t)a.ld_out + n) = v;
   }
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 }
