@@ -114,15 +114,14 @@ def f32_reference(opt, sd, img, imu, ts, steps=5):
         for _ in range(2):
             m(img, imu, ts)
         m.check()
-        m.profile_enable(True)
-        conv_ms = 0.0
+        m.profile_enable(True, depth=steps)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             m(img, imu, ts)
-            conv_ms += m.profile_read()["conv2_6"]
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        conv_ms = m.profile_read()["conv2_6"] * steps
     finally:
         if old is None:
             del os.environ["ODEVIO_CONV_MATH"]
@@ -219,8 +218,9 @@ def main():
     for _ in range(args.warmup):
         step()
     model.check()
-    model.profile_enable(True)
-    stage_ms = {k: 0.0 for k in model.STAGES}
+    # stage timers: a ring of event sets, one per timed step, read AFTER the timed region - reading them per step
+    # would put a host synchronisation (and the next step's launch latency) between the steps being measured
+    model.profile_enable(True, depth=args.steps)
 
     def sync():
         if world > 1:
@@ -231,18 +231,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # reading the events waits for this step only; the next launch queue is refilled immediately
-        for k, v in model.profile_read().items():
-            stage_ms[k] += v
     sync()
     elapsed = time.perf_counter() - t0
+    stage_ms = model.profile_read()   # averages over the K timed steps
     model.check()
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    for k in stage_ms:
-        stage_ms[k] /= args.steps
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps

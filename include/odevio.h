@@ -161,8 +161,11 @@ int odevio_forward_u8(odevio_plan* plan, const uint8_t* img_u8, const float* imu
  * the roofline figures).  Stages: 0 conv1, 1 conv2..conv6 (implicit-GEMM kernel), 2 visual head,
  * 3 inertial encoder + fusion, 4 persistent ODE-RNN integrator, 5 pose regressor. */
 #define ODEVIO_N_STAGES 6
+/* on = 0 switches the timing off; on = d > 0 keeps a ring of d event sets, so up to d forwards can be issued back to
+ * back before the timers are read (reading them must not put a host synchronisation between the forwards). */
 int odevio_profile_enable(odevio_plan* plan, int32_t on);
-/* Waits for the last recorded forward and writes ODEVIO_N_STAGES durations in milliseconds. */
+/* Waits for the last recorded forward and writes ODEVIO_N_STAGES durations in milliseconds, averaged over the forwards
+ * recorded since the previous read (at most the ring depth). */
 int odevio_profile_read(odevio_plan* plan, float* ms_out);
 
 /* Diagnostic build only (make STAMPS=1 -> libodevio_stamps.so): in-kernel phase totals of the last integrator

@@ -90,12 +90,20 @@ struct odevio_plan {
   DevBuf actA, actB, imu_act, fcat, fused, out_seq, reg_hid, partial, hT_scratch;
   std::vector<void*> owned;
   // optional per-stage HIP-event timing of odevio_forward (bench.py's roofline figures)
+  // A ring of event sets: a caller may run many forwards back to back and read the averages afterwards, so that
+  // reading the timers does not put a host synchronisation between the forwards it measures.
   bool prof = false;
-  hipEvent_t ev[ODEVIO_N_STAGES + 1] = {};
+  std::vector<hipEvent_t> ev;   // [depth][ODEVIO_N_STAGES + 1]
+  int ev_depth = 0, ev_w = 0, ev_n = 0;
 };
 
 static void stage_mark(odevio_plan* p, int i, hipStream_t st) {
-  if (p->prof) (void)hipEventRecord(p->ev[i], st);
+  if (!p->prof) return;
+  (void)hipEventRecord(p->ev[(size_t)p->ev_w * (ODEVIO_N_STAGES + 1) + i], st);
+  if (i == ODEVIO_N_STAGES) {   // the forward's last mark: the set is complete
+    p->ev_w = (p->ev_w + 1) % p->ev_depth;
+    if (p->ev_n < p->ev_depth) ++p->ev_n;
+  }
 }
 
 static int dev_alloc(odevio_plan* p, void** out, size_t bytes) {
@@ -213,6 +221,8 @@ extern "C" const char* odevio_last_error(void) { return g_err; }
 
 extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (!p) return;
+  for (hipEvent_t e : p->ev)
+    if (e) (void)hipEventDestroy(e);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
@@ -928,17 +938,34 @@ extern "C" int odevio_reserve(odevio_plan* p, int32_t B, int32_t S, void* stream
 }
 
 extern "C" int odevio_profile_enable(odevio_plan* p, int32_t on) {
-  ARGCHK(p, "odevio_profile_enable: null plan");
-  if (on && !p->ev[0])
-    for (int i = 0; i <= ODEVIO_N_STAGES; ++i) HIPCHK(hipEventCreate(&p->ev[i]));
+  ARGCHK(p && on >= 0 && on <= 4096, "odevio_profile_enable: bad argument");
+  if (on > p->ev_depth) {
+    const size_t have = p->ev.size(), want = (size_t)on * (ODEVIO_N_STAGES + 1);
+    p->ev.resize(want, nullptr);
+    for (size_t i = have; i < want; ++i) HIPCHK(hipEventCreate(&p->ev[i]));
+    p->ev_depth = on;
+  }
   p->prof = on != 0;
+  p->ev_w = 0;
+  p->ev_n = 0;
   return 0;
 }
 
 extern "C" int odevio_profile_read(odevio_plan* p, float* ms_out) {
   ARGCHK(p && ms_out && p->prof, "odevio_profile_read: profiling is not enabled");
-  HIPCHK(hipEventSynchronize(p->ev[ODEVIO_N_STAGES]));
-  for (int i = 0; i < ODEVIO_N_STAGES; ++i) HIPCHK(hipEventElapsedTime(&ms_out[i], p->ev[i], p->ev[i + 1]));
+  if (p->ev_n == 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_profile_read: no complete forward recorded since the last read");
+  for (int i = 0; i < ODEVIO_N_STAGES; ++i) ms_out[i] = 0.f;
+  for (int k = 1; k <= p->ev_n; ++k) {   // the ev_n most recent sets, newest first
+    const hipEvent_t* e = &p->ev[(size_t)((p->ev_w - k + 2 * p->ev_depth) % p->ev_depth) * (ODEVIO_N_STAGES + 1)];
+    HIPCHK(hipEventSynchronize(e[ODEVIO_N_STAGES]));
+    for (int i = 0; i < ODEVIO_N_STAGES; ++i) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, e[i], e[i + 1]));
+      ms_out[i] += ms;
+    }
+  }
+  for (int i = 0; i < ODEVIO_N_STAGES; ++i) ms_out[i] /= (float)p->ev_n;
+  p->ev_n = 0;
   return 0;
 }
 

@@ -396,13 +396,14 @@ class DeepVIO(nn.Module):
 
     STAGES = ("conv1", "conv2_6", "visual_head", "imu_fuse", "integrator", "regressor")
 
-    def profile_enable(self, on=True):
-        """Record HIP events at the stage boundaries of every following forward (on the current stream)."""
+    def profile_enable(self, on=True, depth=1):
+        """Record HIP events at the stage boundaries of every following forward (on the current stream).  ``depth``
+        forwards may be issued back to back before ``profile_read`` (which then returns their average)."""
         self._ensure_plan()
-        _lib.check(self._lib.odevio_profile_enable(self._plan, 1 if on else 0))
+        _lib.check(self._lib.odevio_profile_enable(self._plan, max(1, int(depth)) if on else 0))
 
     def profile_read(self):
-        """Stage durations (ms) of the last forward, keyed by ``STAGES``."""
+        """Stage durations (ms), averaged over the forwards since the last read (at most ``depth``), keyed by ``STAGES``."""
         ms = (ctypes.c_float * len(self.STAGES))()
         _lib.check(self._lib.odevio_profile_read(self._plan, ctypes.cast(ms, ctypes.c_void_p)))
         return dict(zip(self.STAGES, [float(x) for x in ms]))
