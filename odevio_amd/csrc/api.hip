@@ -56,23 +56,6 @@ struct odevio_plan {
   float* conv_scale_h[9] = {};  // BatchNorm scale with the weights' power-of-two pre-scale folded back in
   int conv_math = 1;       // 1: fp16x2 operand split on the fp16 MFMA (default); 0: fp32-input MFMA (ODEVIO_CONV_MATH=f32)
   DevBuf pack_tmp, ingest, partial_side;
-  // odevio_forward as a HIP graph (ODEVIO_GRAPH=1): ~25 dependent launches per forward leave ~10 us gaps each when
-  // issued one by one; replayed as a graph they are dispatched back to back.  Graphs are keyed by the call's pointers
-  // and shapes (PyTorch re-uses a handful of addresses in steady state) and run on a stream owned by the plan that is
-  // event-bridged to the caller's stream (the caller's stream may be the legacy default stream, which cannot capture).
-  struct GraphEntry {
-    const void *img, *imu, *ts, *hc;
-    void *poses, *h_T;
-    int B, S, T, u8;
-    hipGraphExec_t exec;
-    unsigned long long used;
-  };
-  std::vector<GraphEntry> graphs;
-  unsigned long long graph_clock = 0;
-  int graph_on = 0;
-  int warm_B = 0, warm_S = 0, warm_T = 0;   // shape of the last eager forward (its buffers are allocated)
-  hipStream_t gstream = nullptr;
-  hipEvent_t ev_gin = nullptr, ev_gout = nullptr;
   // the inertial encoder runs beside the image encoder on its own stream (odevio_forward)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -240,10 +223,6 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (!p) return;
   for (hipEvent_t e : p->ev)
     if (e) (void)hipEventDestroy(e);
-  for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
-  if (p->gstream) (void)hipStreamDestroy(p->gstream);
-  if (p->ev_gin) (void)hipEventDestroy(p->ev_gin);
-  if (p->ev_gout) (void)hipEventDestroy(p->ev_gout);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
@@ -324,7 +303,6 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   } while (0)
 
   std::vector<float> w, t, sc, sh, bias;
-  if (const char* gm = getenv("ODEVIO_GRAPH")) p->graph_on = atoi(gm) != 0;
   if (const char* cm = getenv("ODEVIO_CONV_MATH")) {  // diagnostic override; the default is the fp32-accurate split
     if (!strcmp(cm, "f32")) p->conv_math = 0;
     else if (!strcmp(cm, "f16x2")) p->conv_math = 1;
@@ -1148,71 +1126,10 @@ extern "C" int odevio_forward_u8(odevio_plan* p, const uint8_t* img, const float
   return forward_any(p, img, true, imu, T, ts, hc, B, S, poses, h_T, stats, stream);
 }
 
-static int forward_body(odevio_plan* p, const void* img, bool img_u8, const float* imu, int32_t T, const float* ts,
-                        const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream);
-
 static int forward_any(odevio_plan* p, const void* img, bool img_u8, const float* imu, int32_t T, const float* ts,
                        const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream) {
   ARGCHK(p && img && imu && ts && poses && h_T && B > 0 && S > 1, "odevio_forward: bad argument");
   if ((T - 1) / 10 != S - 1) return fail(ODEVIO_ERR_BAD_ARG, "imu length %d does not give %d frame pairs", T, S - 1);
-  hipStream_t st = (hipStream_t)stream;
-  const bool graphable = p->graph_on && !p->prof && stats == nullptr;
-  if (!graphable || p->warm_B != B || p->warm_S != S || p->warm_T != T) {
-    // eager: the first forward of a shape allocates the workspace (nothing may allocate inside a capture)
-    int rc = forward_body(p, img, img_u8, imu, T, ts, hc, B, S, poses, h_T, stats, stream);
-    if (rc == 0) { p->warm_B = B; p->warm_S = S; p->warm_T = T; }
-    return rc;
-  }
-  if (!p->gstream) {
-    HIPCHK(hipStreamCreateWithFlags(&p->gstream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&p->ev_gin, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&p->ev_gout, hipEventDisableTiming));
-  }
-  odevio_plan::GraphEntry* hit = nullptr;
-  for (auto& g : p->graphs)
-    if (g.img == img && g.imu == imu && g.ts == ts && g.hc == hc && g.poses == poses && g.h_T == h_T && g.B == B && g.S == S &&
-        g.T == T && g.u8 == (int)img_u8)
-      hit = &g;
-  if (!hit) {
-    hipGraph_t graph = nullptr;
-    HIPCHK(hipStreamBeginCapture(p->gstream, hipStreamCaptureModeThreadLocal));
-    const int rc = forward_body(p, img, img_u8, imu, T, ts, hc, B, S, poses, h_T, nullptr, p->gstream);
-    const hipError_t e = hipStreamEndCapture(p->gstream, &graph);
-    if (rc != 0 || e != hipSuccess || !graph) {
-      if (graph) (void)hipGraphDestroy(graph);
-      p->graph_on = 0;   // never try again on this plan; the eager path is always valid
-      (void)hipGetLastError();
-      return forward_body(p, img, img_u8, imu, T, ts, hc, B, S, poses, h_T, stats, stream);
-    }
-    hipGraphExec_t exec = nullptr;
-    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) {
-      p->graph_on = 0;
-      (void)hipGetLastError();
-      return forward_body(p, img, img_u8, imu, T, ts, hc, B, S, poses, h_T, stats, stream);
-    }
-    if (p->graphs.size() >= 8) {   // evict the least recently used
-      size_t lru = 0;
-      for (size_t i = 1; i < p->graphs.size(); ++i)
-        if (p->graphs[i].used < p->graphs[lru].used) lru = i;
-      (void)hipGraphExecDestroy(p->graphs[lru].exec);
-      p->graphs.erase(p->graphs.begin() + lru);
-    }
-    p->graphs.push_back({img, imu, ts, hc, poses, h_T, B, S, T, (int)img_u8, exec, 0});
-    hit = &p->graphs.back();
-  }
-  hit->used = ++p->graph_clock;
-  HIPCHK(hipEventRecord(p->ev_gin, st));
-  HIPCHK(hipStreamWaitEvent(p->gstream, p->ev_gin, 0));
-  HIPCHK(hipGraphLaunch(hit->exec, p->gstream));
-  HIPCHK(hipEventRecord(p->ev_gout, p->gstream));
-  HIPCHK(hipStreamWaitEvent(st, p->ev_gout, 0));
-  return 0;
-}
-
-static int forward_body(odevio_plan* p, const void* img, bool img_u8, const float* imu, int32_t T, const float* ts,
-                        const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int P = B * (S - 1), F = p->F;
   int rc;
