@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Wall time of DeepVIO.forward at the BASELINE configs[1] shape without any stage timers (pure launch stream).
-Usage: [ODEVIO_GRAPH=1] python tools/time_forward.py [steps]"""
+Usage: python tools/time_forward.py [steps]"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,4 +19,4 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 m.check()
-print(f"ODEVIO_GRAPH={os.environ.get('ODEVIO_GRAPH', '0')}: {dt * 1e3:.3f} ms per forward, {16 * 11 / dt:.0f} frames/s")
+print(f"{dt * 1e3:.3f} ms per forward, {16 * 11 / dt:.0f} frames/s")
