@@ -548,3 +548,27 @@ def test_baseline_config1_full_batch(dev):
         ref_p, ref_h = oc.deepvio_forward(sd, img[b:b + 1], imu[b:b + 1], ts[b:b + 1], None, opt)
         assert_close(poses[b:b + 1], ref_p, what=f"poses of sequence {b}")
         assert_close(h[:, b:b + 1], ref_h, what=f"h_T of sequence {b}")
+
+
+def test_encoder_error_against_fp64_truth(dev, monkeypatch, capsys):
+    """How far the image encoder (conv1..conv6 + visual head, 256x512) is from an fp64 evaluation of the same network,
+    for both arithmetic modes.  The fp16x2 operand split must be as accurate as the fp32-input MFMA path (DESIGN.md 5.1;
+    measured: oracle fp32 9.3e-7, fp32 MFMA 1.37e-6, fp16x2 1.24e-6)."""
+    from odevio_amd import DeepVIO
+    opt = default_opt()
+    sd = weights.make_state_dict(opt, seed=5, randomize_stats=True)
+    img = synth.images(2, 3, 256, 512, seed=1)
+    truth = oc.image_encoder(sd, img, torch.float64)
+    errs = {"oracle_fp32": oc.rel_err(oc.image_encoder(sd, img), truth)}
+    for mode in ("f16x2", "f32"):
+        monkeypatch.setenv("ODEVIO_CONV_MATH", mode)
+        m = DeepVIO(opt, seed=5)
+        m.load_state_dict(sd)
+        m = m.cuda()
+        fv = m.image_encoder(img.cuda())
+        m.check()
+        errs[mode] = oc.rel_err(fv, truth)
+    with capsys.disabled():
+        print("\nimage encoder vs fp64 truth (max err / max):", {k: f"{v:.3e}" for k, v in errs.items()})
+    assert errs["f16x2"] < 5e-6 and errs["f32"] < 5e-6
+    assert errs["f16x2"] < 2.0 * errs["f32"]
