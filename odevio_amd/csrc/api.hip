@@ -87,7 +87,7 @@ struct odevio_plan {
   float *cde_init_w = nullptr, *cde_init_b = nullptr;
   DevBuf cde_ws;
   // workspace (grown on demand)
-  DevBuf actA, actB, imu_act, fcat, fused, out_seq, reg_hid, partial, hT_scratch;
+  DevBuf actA, actB, imu_act, fcat, fused, out_seq, reg_hid, partial;
   std::vector<void*> owned;
   // optional per-stage HIP-event timing of odevio_forward (bench.py's roofline figures)
   // A ring of event sets: a caller may run many forwards back to back and read the averages afterwards, so that
@@ -228,7 +228,7 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->hT_scratch, &p->cde_ws, &p->pack_tmp, &p->ingest, &p->partial_side})
+                    &p->cde_ws, &p->pack_tmp, &p->ingest, &p->partial_side})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
