@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0
 # conv2..conv6 multiply fp32 operands held as two fp16 pieces with 3 fp16 MFMAs per fp32 product:
 # executed MFMA flops = 3 x algorithmic flops.  ODEVIO_CONV_MATH=f32 selects the fp32-input MFMA kernel instead.
 CONV_MATH = os.environ.get("ODEVIO_CONV_MATH", "f16x2")
-MFMA_PER_PRODUCT = {"f16x2": 3, "f32": 1}[CONV_MATH]
+MFMA_PER_PRODUCT = {"f16x2": 3, "f32": 1, "f16": 1}[CONV_MATH]   # "f16": reduced precision (fp16 operands), not the parity path
 
 
 def conv_flops_per_pair():
@@ -252,7 +252,7 @@ def main():
         out = {
             "metric": METRIC, "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if CONV_MATH == "f16" else "f32", "data": "synthetic",
             "dtype_note": "fp32 in, fp32 out, fp32 accumulate everywhere; conv2..conv6 products via " + CONV_MATH + (" operand split: operands to 2^-22, products exact, see DESIGN.md section 4" if CONV_MATH != "f32" else " MFMA"),
             "config": {"workload": f"DeepVIO.forward: {B} sequences x {S} frames 256x512 per GPU, ODEFunc 768-512-512-512-768, "
                                    f"RK4 (3/8) 1 step/interval, 2-layer tanh RNN, fp32 (BASELINE configs[1])" if (args.ode_solver, args.drop) == ("rk4", 0.0)
@@ -269,7 +269,7 @@ def main():
                                     "frac": round(integ_bytes / integ_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("integrator_kernel<4>"),
                                     "note": "latency-bound by design: weights stay in LDS, algorithmic bytes assume a re-read per stage"},
         }
-        if world == 1 and CONV_MATH != "f32" and not args.no_f32_reference:
+        if world == 1 and CONV_MATH == "f16x2" and not args.no_f32_reference:
             out["fp32_mfma_encoder"] = f32_reference(opt, sd, img, imu, ts)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt, sd)

@@ -94,7 +94,8 @@ const char* odevio_last_error(void);
  * order of the fp16-MFMA kernels, pre-scaled by a power of two per layer; plus [Cout][kh][kw][Cin] fp32 for the
  * ODEVIO_CONV_MATH=f32 mode), permutes the visual head to the NHWC flatten order and column-shards the ODEFunc/RNN
  * weights for the persistent integrator.  Replaces: DeepVIO.__init__ + load_state_dict (DeepVIO.py:37-43).
- * Environment (diagnostic): ODEVIO_CONV_MATH = f16x2 (default) | f32, read here. */
+ * Environment: ODEVIO_CONV_MATH = f16x2 (default) | f32 (fp32-input MFMA) | f16 (reduced precision: fp16 encoder
+ * operands, outside the fp32 parity claim), read here. */
 int odevio_plan_create(const odevio_config* cfg, const odevio_tensor* weights, int32_t n_weights, void* stream,
                        odevio_plan** out_plan);
 void odevio_plan_destroy(odevio_plan* plan);

@@ -306,9 +306,10 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   if (const char* cm = getenv("ODEVIO_CONV_MATH")) {  // diagnostic override; the default is the fp32-accurate split
     if (!strcmp(cm, "f32")) p->conv_math = 0;
     else if (!strcmp(cm, "f16x2")) p->conv_math = 1;
+    else if (!strcmp(cm, "f16")) p->conv_math = 2;   // reduced precision: fp16 operands (h piece only), fp32 accumulate
     else {
       odevio_plan_destroy(p);
-      return fail(ODEVIO_ERR_BAD_ARG, "ODEVIO_CONV_MATH must be f16x2 or f32");
+      return fail(ODEVIO_ERR_BAD_ARG, "ODEVIO_CONV_MATH must be f16x2, f32 or f16");
     }
   }
   // ---- image encoder
@@ -620,6 +621,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
       a.planes = g.planes; a.zeros = p->zero_page; a.Hp = g.Hp; a.Wp = g.Wp;
       a.wt16 = p->conv_ws[0];
       a.scale = p->conv_scale_h[0];
+      a.terms = p->conv_math == 2 ? 1 : 3;
       HIPCHK(launch_conv1_f16x2(a, p->n_cu, st));
     } else {
       if (in_u8) return fail(ODEVIO_ERR_UNSUPPORTED, "uint8 frames need the fp16x2 encoder (unset ODEVIO_CONV_MATH=f32)");
@@ -632,7 +634,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.in = in; a.w = p->conv_ws[i]; a.zeros = p->zero_page; a.scale = p->conv_scale_h[i]; a.shift = p->conv_shift[i]; a.out = out; a.status = p->status;
     a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
     a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
-    a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.ld_out = cs.cout;
+    a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.ld_out = cs.cout; a.terms = p->conv_math == 2 ? 1 : 3;
     const int nk = cs.k * cs.k * cs.cin / 32;
     a.splitk = pick_splitk_h(a.M, a.Cout, nk);
     a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
@@ -699,7 +701,7 @@ static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* f
     a.in = cur; a.w = p->head_ws; a.zeros = p->zero_page; a.scale = p->head_scale_h; a.shift = p->head_b; a.out = fv;
     a.status = p->status;
     a.N = P; a.Hi = a.Wi = a.Ho = a.Wo = 1; a.Cin = p->head_k; a.Cout = p->cfg.v_f_len; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
-    a.M = P; a.slope = 1.0f; a.out_split = 0; a.ld_out = ld_fv;
+    a.M = P; a.slope = 1.0f; a.out_split = 0; a.ld_out = ld_fv; a.terms = p->conv_math == 2 ? 1 : 3;
     const int nk = p->head_k / 32;
     a.splitk = pick_splitk_h(a.M, a.Cout, nk);
     a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;

@@ -45,6 +45,7 @@ struct ConvSplitArgs {
   int M;
   float slope;          // LeakyReLU slope (the only epilogue the encoder needs)
   int out_split;
+  int terms;            // 3 (default): h h + h l + l h; 1: h h only (reduced-precision mode)
   int ld_out;           // row stride (floats) of an fp32 output (out_split = 0)
   int splitk, ktiles_per_split;
   int xcd_map;
@@ -70,6 +71,7 @@ struct Conv1Args {
   const float* shift;   // [64]
   void* out;            // NHWC [P][Ho][Wo][64] fp32, or the same pixels in P2 layout (out_split)
   int out_split;
+  int terms;            // 3 / 1 piece pairs per product (two-group kernel)
   int* status;
   int B, S, H, W, Ho, Wo;
   int tiles_y, tiles_x, n_tiles;  // per-pair tile grid and total tile count

@@ -356,6 +356,7 @@ __device__ __forceinline__ bool group_barrier(unsigned* ctr, unsigned& target, i
   return true;
 }
 
+template <int TERMS>   // 3: fp32-grade product; 1: h_w h_x only (ODEVIO_CONV_MATH=f16, see conv_f16x2.hip)
 __global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ws = smem;                                   // [2][42][64][8] fp16
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
       constexpr int PW[3] = {1, 0, 0};
       constexpr int PX[3] = {0, 1, 0};
 #pragma unroll
-      for (int tt = 0; tt < 3; ++tt) {
+      for (int tt = 3 - TERMS; tt < 3; ++tt) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][0][PW[tt]], xf[cur][0][PX[tt]], acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][1][PW[tt]], xf[cur][0][PX[tt]], acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][0][PW[tt]], xf[cur][1][PX[tt]], acc[1][0], 0, 0, 0);
@@ -518,7 +519,9 @@ hipError_t launch_conv1_f16x2(const Conv1Args& a, int n_cu, hipStream_t st) {
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H1_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -527,7 +530,8 @@ hipError_t launch_conv1_f16x2(const Conv1Args& a, int n_cu, hipStream_t st) {
   if (a.out_split && !single) {
     const int pairs_of_tiles = (a.n_tiles + 1) / 2;
     const int grid = n_cu < pairs_of_tiles ? n_cu : pairs_of_tiles;
-    hipLaunchKernelGGL(conv1_f16x2_g2_kernel, dim3(grid), dim3(512), H1G_LDS, st, a);
+    if (a.terms == 1) hipLaunchKernelGGL(conv1_f16x2_g2_kernel<1>, dim3(grid), dim3(512), H1G_LDS, st, a);
+    else hipLaunchKernelGGL(conv1_f16x2_g2_kernel<3>, dim3(grid), dim3(512), H1G_LDS, st, a);
   } else {
     const int grid = n_cu < a.n_tiles ? n_cu : a.n_tiles;
     hipLaunchKernelGGL(conv1_f16x2_kernel, dim3(grid), dim3(256), H1_LDS, st, a);

@@ -40,6 +40,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// TERMS = 3: the fp32-grade product described above.  TERMS = 1 (ODEVIO_CONV_MATH=f16, outside the fp32 parity claim):
+// only h_w h_x, i.e. plain fp16 operands (11-bit significands) with fp32 accumulation - the reduced-precision mode of
+// BASELINE configs[2]; same layout, same kernel, a third of the MFMAs.
+template <int TERMS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_kernel(ConvSplitArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // HSTAGES * HSTAGE = 144 KB
 
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-          for (int t = 0; t < 3; ++t)
+          for (int t = 3 - TERMS; t < 3; ++t)
             acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][PW[t]], xf[i][PX[t]], acc[i][n], 0, 0, 0);
     }
   };
@@ -280,12 +284,15 @@ hipError_t launch_conv_f16x2(const ConvSplitArgs& a_in, hipStream_t st) {
   const size_t lds = (size_t)HSTAGES * HSTAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   (void)hipGetLastError();
-  hipLaunchKernelGGL(conv_f16x2_kernel, grid, dim3(512), lds, st, a);
+  if (a.terms == 1) hipLaunchKernelGGL(conv_f16x2_kernel<1>, grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(conv_f16x2_kernel<3>, grid, dim3(512), lds, st, a);
   if (a.splitk > 1) {
     const size_t total4 = (size_t)a.M * a.Cout / 4;
     int blocks = (int)((total4 + 255) / 256);
