@@ -635,8 +635,17 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
     a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
     a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.ld_out = cs.cout; a.terms = p->conv_math == 2 ? 1 : 3;
+    {  // 256 x 256 tiles (a third fewer staged bytes per flop) where they fill whole rounds of the chip: measured
+       // conv3 1400 -> 1204 us and conv3_1 1012 -> 922 us (1280 tiles = 5.0 rounds of 256 CUs), but conv4 / conv4_1
+       // +6 % (640 tiles = 2.5 rounds: the half-empty last round costs more than the saved bytes)
+      static const char* wenv = getenv("ODEVIO_WIDE");   // diagnostic: 0 = never, 1 = whenever Cout % 256 == 0
+      const long wide_tiles = (long)((a.M + 255) / 256) * (a.Cout / 256);
+      const double rounds = (double)wide_tiles / p->n_cu;
+      const bool fills = wide_tiles >= 2L * p->n_cu && rounds / std::ceil(rounds) >= 0.9;
+      a.wide = a.Cout % 256 == 0 && (wenv ? atoi(wenv) != 0 : fills);
+    }
     const int nk = cs.k * cs.k * cs.cin / 32;
-    a.splitk = pick_splitk_h(a.M, a.Cout, nk);
+    a.splitk = a.wide ? 1 : pick_splitk_h(a.M, a.Cout, nk);
     a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
     a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
     if (a.splitk > 1) {

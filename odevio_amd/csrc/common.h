@@ -46,6 +46,7 @@ struct ConvSplitArgs {
   float slope;          // LeakyReLU slope (the only epilogue the encoder needs)
   int out_split;
   int terms;            // 3 (default): h h + h l + l h; 1: h h only (reduced-precision mode)
+  int wide;             // 256 x 256 output tiles (Cout % 256 == 0) instead of 256 x 128
   int ld_out;           // row stride (floats) of an fp32 output (out_split = 0)
   int splitk, ktiles_per_split;
   int xcd_map;

@@ -36,6 +36,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define HA_BYTES (HBM_ * HROW)
 #define HSTAGE ((HBM_ + HBN_) * HROW)   // 48 KB
 #define HSTAGES 3
+#define HBNW_ 256           // the wide variant's channel tile
+#define HSTAGEW ((HBM_ + HBNW_) * HROW)   // 64 KB
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -252,6 +254,216 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 }
 
+// The same kernel with a 256 x 256 output tile (each wave 64 pixels x 128 channels) for layers with Cout % 256 == 0 and
+// enough tiles to fill the chip.  Why: with one MFMA per product (TERMS = 1) the 256 x 128 kernel still needs 4.0 of its
+// 6.3 ms - the L2 -> LDS staging stream (52 GB per forward, ~13 TB/s) is a second ceiling right under the MFMA/power one.
+// A 256 x 256 tile moves a third fewer bytes per flop.  Two 64 KB stages (the DMA of tile j+1 runs under the 96 MFMAs per
+// wave of tile j); the weight fragments are read in two halves to stay inside 256 registers.
+template <int TERMS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_wide_kernel(ConvSplitArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 * HSTAGEW = 128 KB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: see conv_igemm_kernel
+  const int NT = gridDim.y;
+  int mt_idx = blockIdx.x, nt_idx = blockIdx.y;
+  if (a.xcd_map) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int chunk = gridDim.x >> 3;
+    mt_idx = xcd * chunk + slot / NT;
+    nt_idx = slot - (slot / NT) * NT;
+  }
+  if (mt_idx * HBM_ >= a.M) return;
+  const int m0 = mt_idx * HBM_;
+  const int n0 = nt_idx * HBNW_;
+
+  // ---- loader role.  One DMA instruction = 8 rows x 8 pieces of 16 B; lane l brings LDS slot (l & 7) of row
+  // (l >> 3), which holds source piece slot ^ ((row >> 1) & 7).  Wave w stages pixel rows 32w .. 32w+31 (4 DMAs) and
+  // weight rows 16w .. 16w+15 (2 DMAs) of every K-tile.
+  const int groups = a.Cin >> 5;            // 32-channel groups per pixel
+  const int taps = a.KH * a.KW;
+  const int nk = taps * groups;             // K-tiles: (channel group, tap), tap minor
+  const int px_bytes = groups * HROW;
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(a.in);
+  const unsigned char* w_b = reinterpret_cast<const unsigned char*>(a.w);
+  const int lr = lane >> 3, lslot = lane & 7;
+  const unsigned char* a_row[4];
+  int a_hi0[4], a_wi0[4];
+  int a_poff[4];                            // byte offset of this lane's source piece inside the 128-byte block
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 32 * wave + 8 * q + lr;   // row of the pixel tile
+    a_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
+    const int m = m0 + r;
+    if (m < a.M) {
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      a_hi0[q] = ho * a.stride - a.pad;
+      a_wi0[q] = wo * a.stride - a.pad;
+      a_row[q] = in_b + ((ptrdiff_t)img * a.Hi * a.Wi + (ptrdiff_t)a_hi0[q] * a.Wi + a_wi0[q]) * px_bytes + a_poff[q];
+    } else {
+      a_row[q] = in_b;
+      a_hi0[q] = -(1 << 28);
+      a_wi0[q] = -(1 << 28);
+    }
+  }
+  const unsigned char* b_row[4];
+  int b_poff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 32 * wave + 8 * q + lr;   // row of the weight tile
+    b_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
+    const int n = n0 + r;
+    b_row[q] = (n < a.Cout) ? w_b + (size_t)n * nk * HROW + b_poff[q] : nullptr;
+  }
+  const unsigned char* zero_b = reinterpret_cast<const unsigned char*>(a.zeros);
+
+  int kt_begin = 0, kt_end = nk;
+  if (a.splitk > 1) {
+    kt_begin = blockIdx.z * a.ktiles_per_split;
+    kt_end = min(nk, kt_begin + a.ktiles_per_split);
+  }
+
+  // K-tile walk (workgroup-uniform): channel group MAJOR, tap MINOR (the taps of one group re-read the same pixels
+  // shifted by one, back to back: L1/L2 hits), without divisions.
+  int t_kh = 0, t_kw = 0, t_g = 0, t_aoff = 0, t_boff = 0;
+  {
+    const int g = kt_begin / taps;
+    const int tap = kt_begin - g * taps;
+    t_g = g;
+    t_kh = tap / a.KW;
+    t_kw = tap - t_kh * a.KW;
+    t_aoff = (t_kh * a.Wi + t_kw) * px_bytes + g * HROW;
+    t_boff = kt_begin * HROW;
+  }
+  auto next_tile = [&]() {
+    ++t_kw;
+    t_aoff += px_bytes;
+    t_boff += HROW;
+    if (t_kw == a.KW) {
+      t_kw = 0;
+      ++t_kh;
+      t_aoff += (a.Wi - a.KW) * px_bytes;
+      if (t_kh == a.KH) {
+        t_kh = 0;
+        ++t_g;
+        t_aoff = t_g * HROW;
+      }
+    }
+  };
+  // 8 DMAs per wave and tile; the LDS destination is wave-uniform (+ lane * 16 by the hardware)
+  auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+    unsigned char* dst = lds + stage * HSTAGEW;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = (unsigned)(a_hi0[q] + t_kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + t_kw) < (unsigned)a.Wi;
+      const unsigned char* pa = ok ? a_row[q] + t_aoff : zero_b + a_poff[q];
+      __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + (32 * wave + 8 * q) * HROW), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned char* pb = b_row[q] ? b_row[q] + t_boff : zero_b + b_poff[q];
+      __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + HA_BYTES + (32 * wave + 8 * q) * HROW), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][8];   // [pixel block of 16][channel block of 16]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads.  16x16x32 MFMA: lane (fi, fh) holds row fi of a 16-row block, channels 8 fh .. 8 fh + 7 of the
+  // 32-channel K-tile: source piece c = 4 * piece + fh, LDS slot c ^ ((row >> 1) & 7); block bases are multiples of 16
+  // rows, so the permutation only depends on fi.  Conflict-free per ds_read_b128 lane group.
+  const int fi = lane & 15, fh = lane >> 4;
+  const int fsw = (fi >> 1) & 7;
+  const int a_base = (wm * 64 + fi) * HROW;
+  const int b_base = HA_BYTES + (wn * 128 + fi) * HROW;
+
+  // D rows = output channels (weights are the MFMA's A operand), D columns = pixels: a lane ends up with 4
+  // consecutive channels of one pixel per register group (one vector store each in the epilogue).
+  auto multiply = [&](int stage) __attribute__((always_inline)) {
+    const unsigned char* Ab = lds + stage * HSTAGEW + a_base;
+    const unsigned char* Bb = lds + stage * HSTAGEW + b_base;
+    f16x8 xf[4][2];   // [block][piece]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int off = ((4 * p + fh) ^ fsw) * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[i][p] = *reinterpret_cast<const f16x8*>(Ab + i * 16 * HROW + off);
+    }
+    constexpr int PW[3] = {1, 0, 0};   // l_w h_x, h_w l_x, h_w h_x: small contributions first
+    constexpr int PX[3] = {0, 1, 0};
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      f16x8 wf[4][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int off = ((4 * p + fh) ^ fsw) * 16;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) wf[n][p] = *reinterpret_cast<const f16x8*>(Bb + (4 * nh + n) * 16 * HROW + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int t = 3 - TERMS; t < 3; ++t)
+            acc[i][4 * nh + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][PW[t]], xf[i][PX[t]], acc[i][4 * nh + n], 0, 0, 0);
+    }
+  };
+
+  const int ntile = kt_end - kt_begin;
+  // Two stages: tile j is multiplied while the DMA of tile j+1 fills the other stage (which everybody finished reading
+  // before the barrier that ended step j-1).  Past the end the last tile is fetched again (unused): exact counts.
+  issue_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int j = 0; j < ntile; ++j) {
+    if (j + 1 < ntile) next_tile();
+    issue_tile((j + 1) & 1);
+    multiply(j & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue.  C/D map of the 16x16 MFMA: column (= pixel) = lane&15, row (= channel) = 4*(lane>>4) + r
+  bool range_bad = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fi;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int nb4 = 0; nb4 < 8; ++nb4) {
+      const int n = n0 + wn * 128 + nb4 * 16 + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
+      if (n >= a.Cout) continue;
+      f32x4 v = acc[i][nb4];
+      if (a.splitk > 1) {
+        *reinterpret_cast<f32x4*>(a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
+      } else {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = v[e] * sc[e] + sh[e];
+          v[e] = x > 0.f ? x : x * a.slope;
+        }
+        if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
+        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ld_out + n) = v;
+      }
+    }
+  }
+  if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
+}
+
 // Deterministic split-K combine: sums the slabs in slab order, then the same epilogue; 4 channels per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_f16x2_kernel(ConvSplitArgs a) {
   const size_t total4 = (size_t)a.M * a.Cout / 4;
@@ -280,18 +492,26 @@ hipError_t launch_conv_f16x2(const ConvSplitArgs& a_in, hipStream_t st) {
   ConvSplitArgs a = a_in;
   const int mt = (a.M + HBM_ - 1) / HBM_;
   a.xcd_map = mt >= 16;
-  dim3 grid(a.xcd_map ? (mt + 7) / 8 * 8 : mt, (a.Cout + HBN_ - 1) / HBN_, a.splitk > 1 ? a.splitk : 1);
-  const size_t lds = (size_t)HSTAGES * HSTAGE;
+  const int bn = a.wide ? HBNW_ : HBN_;
+  dim3 grid(a.xcd_map ? (mt + 7) / 8 * 8 : mt, (a.Cout + bn - 1) / bn, a.splitk > 1 ? a.splitk : 1);
+  const size_t lds = a.wide ? (size_t)2 * HSTAGEW : (size_t)HSTAGES * HSTAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, HSTAGES * HSTAGE);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, HSTAGES * HSTAGE);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGEW);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGEW);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   (void)hipGetLastError();
-  if (a.terms == 1) hipLaunchKernelGGL(conv_f16x2_kernel<1>, grid, dim3(512), lds, st, a);
+  if (a.wide) {
+    if (a.terms == 1) hipLaunchKernelGGL(conv_f16x2_wide_kernel<1>, grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(conv_f16x2_wide_kernel<3>, grid, dim3(512), lds, st, a);
+  } else if (a.terms == 1) hipLaunchKernelGGL(conv_f16x2_kernel<1>, grid, dim3(512), lds, st, a);
   else hipLaunchKernelGGL(conv_f16x2_kernel<3>, grid, dim3(512), lds, st, a);
   if (a.splitk > 1) {
     const size_t total4 = (size_t)a.M * a.Cout / 4;

@@ -22,7 +22,7 @@ def main():
         print(f"{r[0][:60]:60s} calls {r[1]:5d} avg {r[3] / 1e3:10.1f} us  {100 * r[2] / tot:6.2f} %")
     if "--last-forward" in sys.argv:
         seq = list(c.execute("select name, grid_x, grid_y, grid_z, workgroup_x, end-start from kernels order by start"))
-        idx = [i for i, r in enumerate(seq) if r[0].startswith("conv1")]
+        idx = [i for i, r in enumerate(seq) if r[0].startswith("ingest") or r[0].startswith("conv1_kernel")]
         for r in seq[idx[-1]:idx[-1] + 32]:
             print(f"  {r[0][:48]:48s} grid {r[1] // r[4]:6d} x {r[2]:3d} x {r[3]:3d}  {r[5] / 1e3:9.1f} us")
 
