@@ -68,7 +68,7 @@ def conv_roofline(conv_tflops):
     if CONV_MATH == "f32":
         peak, kern, key = FP32_MFMA_PEAK_TFLOPS, "conv_igemm_kernel (conv2..conv6, fp32-input MFMA)", "conv_igemm_kernel [dispatches > 0.4 ms]"
     else:
-        peak, kern, key = F16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT, "conv_f16x2_kernel (conv2..conv6)", "conv_f16x2_kernel"
+        peak, kern, key = F16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT, "conv_f16x2_kernel / conv_f16x2_wide_kernel (conv2..conv6 + visual head)", "conv_f16x2_"
     return {"kernel": kern, "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(conv_tflops / peak, 4), "traffic": pmc_traffic(key),
             "pmc": pmc_derived("conv_f16x2") if CONV_MATH != "f32" else None,
@@ -95,8 +95,9 @@ def pmc_traffic(kernel_key):
     Counters cannot be read from inside the timed run, so this is the last profiled value, or None."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
-        k = json.load(open(path))["kernels"][kernel_key]
-        return int(k["fetch_bytes"] + k["write_bytes"])
+        ks = json.load(open(path))["kernels"]
+        hit = [v for k, v in ks.items() if k.startswith(kernel_key)]   # template instances / tile variants of one kernel
+        return int(sum(v["fetch_bytes"] + v["write_bytes"] for v in hit)) if hit else None
     except Exception:
         return None
 
@@ -266,7 +267,7 @@ def main():
             "roofline": conv_roofline(conv_tflops),
             "roofline_integrator": {"kernel": "integrator_kernel", "bound": "hbm",
                                     "achieved": round(integ_bytes / integ_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(integ_bytes / integ_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("integrator_kernel<4>"),
+                                    "frac": round(integ_bytes / integ_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("integrator_kernel"),
                                     "note": "latency-bound by design: weights stay in LDS, algorithmic bytes assume a re-read per stage"},
         }
         if world == 1 and CONV_MATH == "f16x2" and not args.no_f32_reference:
