@@ -187,12 +187,22 @@ def main():
     ap.add_argument("--drop", type=float, default=0.0, help="frame-drop probability of the synthetic timestamps")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start one rank per GPU as CHILD processes (torch.distributed.run), before
+        # anything in this process touches the GPU, relay rank 0's JSON line and exit with the launcher's code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dist = None

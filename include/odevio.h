@@ -41,7 +41,8 @@ enum odevio_status {
   ODEVIO_ERR_NO_DEVICE = -5,
   ODEVIO_ERR_TIMEOUT = -6,      /* a bounded in-kernel wait gave up (reported by odevio_check)*/
   ODEVIO_ERR_MAX_STEPS = -7,    /* adaptive solver exceeded max_steps (reported by check)     */
-  ODEVIO_ERR_RANGE = -8         /* an encoder activation left the fp16x2 range (reported by check) */
+  ODEVIO_ERR_RANGE = -8,        /* an encoder activation left the fp16x2 range (reported by check) */
+  ODEVIO_ERR_BOUNDS = -9        /* audit build only (make AUDIT=1): a kernel computed an address outside its buffers */
 };
 
 /* reference src/models/ODEFunc.py:23-36 */
@@ -88,6 +89,12 @@ typedef struct odevio_tensor {
 
 int odevio_version(void);
 const char* odevio_last_error(void);
+/* Audit build (make -C odevio_amd/csrc AUDIT=1 -> libodevio_audit.so, selected with ODEVIO_LIB=): number of plans /
+ * checks of this process that saw an out-of-bounds address computed by a kernel (the access itself is redirected, so
+ * nothing faults).  Always 0 in the production library, whose kernels carry no such checks.  No reference counterpart:
+ * the reference's PyTorch ops are bounds-safe by construction; this is how the hand-written LDS-DMA kernels are held
+ * to the same standard. */
+int odevio_audit_violations(void);
 
 /* Builds a plan: validates the config, finds every weight by name, folds BatchNorm running stats
  * into per-channel (scale, shift), re-lays the convolution weights (two fp16 pieces per fp32 weight in the K-tile
@@ -102,7 +109,10 @@ void odevio_plan_destroy(odevio_plan* plan);
 /* Pre-allocates the activation workspace for batches up to (B, S) so that later calls allocate nothing. */
 int odevio_reserve(odevio_plan* plan, int32_t B, int32_t S, void* stream);
 /* Synchronises `stream` and returns the device status words: an integrator timeout / step-budget overflow, or an
- * encoder activation outside the fp16x2 range (ODEVIO_ERR_RANGE).  Clears what it reports. */
+ * encoder activation outside the fp16x2 range (ODEVIO_ERR_RANGE).  Clears what it reports.
+ * Without this call a failure still surfaces: every forward copies the status words to pinned host memory behind
+ * itself (asynchronously, no host synchronisation), and the next entry point that finds that copy complete returns the
+ * error of the forward before it. */
 int odevio_check(odevio_plan* plan, void* stream);
 
 /* ImageEncoder.forward (Encoder.py:97-122): img [B,S,3,H,W] -> fv [B,S-1,v_f_len] with row stride ld_fv. */

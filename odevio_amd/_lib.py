@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODEVIO_LIB", os.path.join(_HERE, "libodevio.so"))  # ODEVIO_LIB: diagnostic builds
 
 ODEVIO_OK = 0
-ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_MISSING_WEIGHT, ERR_HIP, ERR_NO_DEVICE, ERR_TIMEOUT, ERR_MAX_STEPS, ERR_RANGE = range(-1, -9, -1)
+ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_MISSING_WEIGHT, ERR_HIP, ERR_NO_DEVICE, ERR_TIMEOUT, ERR_MAX_STEPS, ERR_RANGE, ERR_BOUNDS = range(-1, -10, -1)
 
 ACTIVATIONS = {"tanh": 0, "relu": 1, "leaky_relu": 2, "softplus": 3}
 SOLVERS = {"dopri5": 0, "heun": 1, "tsit5": 2, "euler": 3, "rk4": 4, "runge_kutta": 4, "rk4_classic": 5}
@@ -20,7 +20,7 @@ SYMBOLS = [
     "odevio_version", "odevio_last_error", "odevio_plan_create", "odevio_plan_destroy", "odevio_reserve",
     "odevio_check", "odevio_conv_block_fwd", "odevio_image_encoder_fwd", "odevio_imu_encoder_fwd", "odevio_fuse_fwd", "odevio_ode_func",
     "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
-    "odevio_path_accu", "odevio_forward_u8",
+    "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations",
 ]
 
 
@@ -69,6 +69,7 @@ def load():
             raise ImportError(f"libodevio.so does not export {s}")
     vp, i32, fp = ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p
     lib.odevio_version.restype = ctypes.c_int
+    lib.odevio_audit_violations.restype = ctypes.c_int
     lib.odevio_last_error.restype = ctypes.c_char_p
     lib.odevio_plan_create.argtypes = [ctypes.POINTER(OdevioConfig), ctypes.POINTER(OdevioTensor), i32, vp,
                                        ctypes.POINTER(vp)]

@@ -53,6 +53,7 @@ struct odevio_plan {
   // encoder
   float* conv_w[9] = {};
   void* conv_ws[9] = {};   // conv2..conv6 weights as two fp16 pieces (conv_f16x2.hip), [Cout][K-tile][2][32], pre-scaled
+  size_t conv_ws_bytes[9] = {}, head_ws_bytes = 0;
   float* conv_scale_h[9] = {};  // BatchNorm scale with the weights' power-of-two pre-scale folded back in
   int conv_math = 1;       // 1: fp16x2 operand split on the fp16 MFMA (default); 0: fp32-input MFMA (ODEVIO_CONV_MATH=f32)
   DevBuf pack_tmp, ingest, partial_side;
@@ -82,6 +83,11 @@ struct odevio_plan {
   unsigned long long* xbuf = nullptr;
   int xstride = 0;
   int* status = nullptr;
+  // status words copied to pinned host memory behind every forward (no host synchronisation): the next API call that
+  // finds the copy complete reports a failure of the previous forward instead of computing on garbage
+  int* status_host = nullptr;
+  hipEvent_t ev_status = nullptr;
+  bool status_pending = false;
   // Neural-CDE path (model_type cde)
   CdeModel cde = {};
   float *cde_init_w = nullptr, *cde_init_b = nullptr;
@@ -126,6 +132,18 @@ static int ensure(DevBuf& b, size_t n) {
   HIPCHK(hipMalloc((void**)&b.p, n * sizeof(float)));
   b.n = n;
   return 0;
+}
+
+// Bytes from `ptr` to the end of the plan-owned buffer that contains it (what a kernel may touch), or `fallback` for
+// memory the caller owns (its extent is the caller's contract).
+static size_t extent_of(const odevio_plan* p, const void* ptr, size_t fallback) {
+  const DevBuf* bufs[] = {&p->actA, &p->actB, &p->pack_tmp, &p->partial, &p->partial_side, &p->ingest, &p->fcat, &p->fused, &p->out_seq};
+  const uintptr_t a = (uintptr_t)ptr;
+  for (const DevBuf* b : bufs) {
+    const uintptr_t lo = (uintptr_t)b->p, hi = lo + b->n * sizeof(float);
+    if (b->p && a >= lo && a < hi) return hi - a;
+  }
+  return fallback;
 }
 
 struct WeightTable {
@@ -216,13 +234,24 @@ static void shard_columns(const std::vector<float>& W, int N, const std::vector<
     }
 }
 
+static int g_audit_violations = 0;
 extern "C" int odevio_version(void) { return ODEVIO_VERSION; }
+extern "C" int odevio_audit_violations(void) { return g_audit_violations; }
 extern "C" const char* odevio_last_error(void) { return g_err; }
 
 extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (!p) return;
   for (hipEvent_t e : p->ev)
     if (e) (void)hipEventDestroy(e);
+  if (p->status) {   // audit builds: a violation nobody asked about must still be seen (tests/conftest.py)
+    int hw[8] = {};
+    if (hipMemcpy(hw, p->status, sizeof(hw), hipMemcpyDeviceToHost) == hipSuccess && hw[ODEVIO_STATUS_AUDIT]) {
+      ++g_audit_violations;
+      fprintf(stderr, "libodevio AUDIT: kernel id %d computed an address outside its buffers\n", hw[ODEVIO_STATUS_AUDIT + 1]);
+    }
+  }
+  if (p->status_host) (void)hipHostFree(p->status_host);
+  if (p->ev_status) (void)hipEventDestroy(p->ev_status);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
@@ -313,8 +342,8 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
     }
   }
   // ---- image encoder
-  TRY(dev_alloc(p, &p->zero_page, 256));
-  HIPCHK(hipMemsetAsync(p->zero_page, 0, 256, st));
+  TRY(dev_alloc(p, &p->zero_page, ODEVIO_ZERO_PAGE_BYTES));
+  HIPCHK(hipMemsetAsync(p->zero_page, 0, ODEVIO_ZERO_PAGE_BYTES, st));
   p->conv_h[0] = cfg->img_h;
   p->conv_w_sp[0] = cfg->img_w;
   for (int i = 0; i < 9; ++i) {
@@ -356,6 +385,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
               memcpy(&ws[base], &h, 2);
               memcpy(&ws[(size_t)42 * 64 * 8 + base], &l, 2);
             }
+      p->conv_ws_bytes[0] = ws.size() * sizeof(uint16_t);
       TRY(dev_alloc(p, &p->conv_ws[0], ws.size() * sizeof(uint16_t)));
       HIPCHK(hipMemcpyAsync(p->conv_ws[0], ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -363,6 +393,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
     if (i > 0) {
       std::vector<uint16_t> ws;
       prescale = split_conv_weights(w, cs.cout, cs.cin, cs.k * cs.k, ws);
+      p->conv_ws_bytes[i] = ws.size() * sizeof(uint16_t);
       TRY(dev_alloc(p, &p->conv_ws[i], ws.size() * sizeof(uint16_t)));
       HIPCHK(hipMemcpyAsync(p->conv_ws[i], ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -393,6 +424,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
     {  // the same matrix as two fp16 pieces (K = (H,W,C) order = the P2 layout of conv6's output, one 'pixel' per pair)
       std::vector<uint16_t> ws;
       const float prescale = split_conv_weights(t, cfg->v_f_len, p->head_k, 1, ws);
+      p->head_ws_bytes = ws.size() * sizeof(uint16_t);
       TRY(dev_alloc(p, &p->head_ws, ws.size() * sizeof(uint16_t)));
       HIPCHK(hipMemcpyAsync(p->head_ws, ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -525,6 +557,9 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   TRY(dev_alloc(p, (void**)&p->xbuf, (size_t)INTEG_GROUPS * 2 * p->xstride * sizeof(unsigned long long)));
   TRY(dev_alloc(p, (void**)&p->status, 128));
   HIPCHK(hipMemsetAsync(p->status, 0, 128, st));
+  HIPCHK(hipHostMalloc((void**)&p->status_host, 8 * sizeof(int), hipHostMallocDefault));
+  memset(p->status_host, 0, 8 * sizeof(int));
+  HIPCHK(hipEventCreateWithFlags(&p->ev_status, hipEventDisableTiming));
   HIPCHK(hipStreamSynchronize(st));
 #undef TRY
   *out_plan = p;
@@ -616,9 +651,11 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
       g.Hp = 16 * a.tiles_y + 8; g.Wp = 64 * a.tiles_x + 8;
       int rc = ensure(p->ingest, (size_t)g.n_frames * 3 * g.Hp * g.Wp);   // 2 pieces x 2 bytes = one float per pixel
       if (rc) return rc;
-      g.planes = p->ingest.p;
+      g.planes = p->ingest.p; g.planes_bytes = p->ingest.n * sizeof(float); g.status = p->status;
       launch_ingest(g, st);
       a.planes = g.planes; a.zeros = p->zero_page; a.Hp = g.Hp; a.Wp = g.Wp;
+      a.planes_bytes = g.planes_bytes;
+      a.out_bytes = extent_of(p, out, (size_t)P * a.Ho * a.Wo * 64 * sizeof(float));
       a.wt16 = p->conv_ws[0];
       a.scale = p->conv_scale_h[0];
       a.terms = p->conv_math == 2 ? 1 : 3;
@@ -635,6 +672,9 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
     a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
     a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.ld_out = cs.cout; a.terms = p->conv_math == 2 ? 1 : 3;
+    a.in_bytes = extent_of(p, in, (size_t)P * a.Hi * a.Wi * a.Cin * sizeof(float));
+    a.w_bytes = p->conv_ws_bytes[i];
+    a.out_bytes = extent_of(p, out, (size_t)a.M * a.Cout * sizeof(float));
     {  // 256 x 256 tiles (a third fewer staged bytes per flop) where they fill whole rounds of the chip: measured
        // conv3 1400 -> 1204 us and conv3_1 1012 -> 922 us (1280 tiles = 5.0 rounds of 256 CUs), but conv4 / conv4_1
        // +6 % (640 tiles = 2.5 rounds: the half-empty last round costs more than the saved bytes)
@@ -652,6 +692,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
       int rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout);
       if (rc) return rc;
       a.partial = p->partial.p;
+      a.partial_bytes = p->partial.n * sizeof(float);
     }
     HIPCHK(launch_conv_f16x2(a, st));
     return 0;
@@ -718,7 +759,11 @@ static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* f
     if (a.splitk > 1) {
       if ((rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout))) return rc;
       a.partial = p->partial.p;
+      a.partial_bytes = p->partial.n * sizeof(float);
     }
+    a.in_bytes = extent_of(p, cur, (size_t)P * p->head_k * sizeof(float));
+    a.w_bytes = p->head_ws_bytes;
+    a.out_bytes = extent_of(p, fv, ((size_t)(P - 1) * ld_fv + a.Cout) * sizeof(float));
     HIPCHK(launch_conv_f16x2(a, st));
     rc = 0;
   } else {
@@ -994,37 +1039,72 @@ extern "C" int odevio_debug_stamps(odevio_plan* p, uint64_t* out8, void* stream)
   return 0;
 }
 
-extern "C" int odevio_check(odevio_plan* p, void* stream) {
-  ARGCHK(p, "odevio_check: null plan");
-  hipStream_t st = (hipStream_t)stream;
-  int hw[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(hw, p->status, sizeof(hw), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+// Turns the device status words into an error (and clears what it reports on the device, stream-ordered).
+static int report_status(odevio_plan* p, const int* hw, hipStream_t st) {
+  if (hw[ODEVIO_STATUS_AUDIT] != 0) {
+    ++g_audit_violations;
+    const int id = hw[ODEVIO_STATUS_AUDIT + 1];
+    HIPCHK(hipMemsetAsync(p->status + ODEVIO_STATUS_AUDIT, 0, 2 * sizeof(int), st));
+    return fail(ODEVIO_ERR_BOUNDS, "audit build: kernel id %d computed an address outside its buffers (access redirected)", id);
+  }
   if (hw[ODEVIO_STATUS_RANGE] != 0) {
     HIPCHK(hipMemsetAsync(p->status + ODEVIO_STATUS_RANGE, 0, sizeof(int), st));
-    HIPCHK(hipStreamSynchronize(st));
     return fail(ODEVIO_ERR_RANGE, "image encoder: an activation left the fp16x2 range (|x| > 65504 or not finite); "
                                   "set ODEVIO_CONV_MATH=f32 for the fp32-input MFMA path");
   }
   if (hw[ODEVIO_STATUS_RANGE + 1] != 0) {
     HIPCHK(hipMemsetAsync(p->status + ODEVIO_STATUS_RANGE + 1, 0, sizeof(int), st));
-    HIPCHK(hipStreamSynchronize(st));
     return fail(ODEVIO_ERR_TIMEOUT, "conv1: a bounded in-kernel group barrier gave up");
   }
   const int h = hw[0];
   if (h != 0) {
     HIPCHK(hipMemsetAsync(p->status, 0, sizeof(int), st));
-    HIPCHK(hipStreamSynchronize(st));
-    return fail(h, h == ODEVIO_ERR_TIMEOUT ? "integrator: a bounded in-kernel wait timed out"
-                                           : "integrator: adaptive solver exceeded max_steps");
+    return fail(h, h == ODEVIO_ERR_TIMEOUT ? "integrator: a bounded in-kernel wait timed out (are all 256 workgroups resident?)"
+                                           : "solver exceeded max_steps");
   }
   return 0;
+}
+
+// Behind a forward: status words -> pinned host memory, asynchronously.  At an API entry: if that copy has completed and
+// shows a failure, report it now (the outputs of that forward are garbage and every later launch would bail out early).
+static void post_status(odevio_plan* p, hipStream_t st) {
+  if (!p->status_host) return;
+  if (hipMemcpyAsync(p->status_host, p->status, 8 * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+      hipEventRecord(p->ev_status, st) == hipSuccess)
+    p->status_pending = true;
+}
+static int poll_status(odevio_plan* p, hipStream_t st) {
+  if (!p->status_pending || hipEventQuery(p->ev_status) != hipSuccess) return 0;
+  p->status_pending = false;
+  int hw[8];
+  memcpy(hw, p->status_host, sizeof(hw));
+  return report_status(p, hw, st);
+}
+#define POLL(p, st)                                  \
+  do {                                               \
+    const int rc_ = poll_status((p), (hipStream_t)(st)); \
+    if (rc_) return rc_;                             \
+  } while (0)
+
+extern "C" int odevio_check(odevio_plan* p, void* stream) {
+  ARGCHK(p, "odevio_check: null plan");
+  hipStream_t st = (hipStream_t)stream;
+  int hw[8] = {};
+  HIPCHK(hipMemcpyAsync(hw, p->status, sizeof(hw), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  p->status_pending = false;
+  const int rc = report_status(p, hw, st);
+  if (rc) HIPCHK(hipStreamSynchronize(st));
+  return rc;
 }
 
 extern "C" int odevio_image_encoder_fwd(odevio_plan* p, const float* img, int32_t B, int32_t S, float* fv,
                                         int32_t ld_fv, void* stream) {
   ARGCHK(p && img && fv && B > 0 && S > 1 && ld_fv >= p->cfg.v_f_len, "odevio_image_encoder_fwd: bad argument");
-  return image_encoder(p, img, B, S, fv, ld_fv, (hipStream_t)stream);
+  POLL(p, stream);
+  const int rc = image_encoder(p, img, B, S, fv, ld_fv, (hipStream_t)stream);
+  post_status(p, (hipStream_t)stream);
+  return rc;
 }
 
 extern "C" int odevio_conv_block_fwd(odevio_plan* p, int32_t layer, const float* in, int32_t B, int32_t S, float* out,
@@ -1073,13 +1153,14 @@ extern "C" int odevio_ode_steps(odevio_plan* p, const float* y, const float* t0,
   if (solver < 0) solver = p->cfg.ode_solver;
   if (solver > ODEVIO_RK4_CLASSIC) return fail(ODEVIO_ERR_BAD_ARG, "Solver not supported");
   if (substeps <= 0) substeps = p->cfg.ode_substeps;
-  return run_rows(p, MODE_ODE_STEPS, y, t0, t1, rows, solver, substeps, y_out, stats, (hipStream_t)stream);
+  POLL(p, stream);
+  const int rc = run_rows(p, MODE_ODE_STEPS, y, t0, t1, rows, solver, substeps, y_out, stats, (hipStream_t)stream);
+  post_status(p, (hipStream_t)stream);
+  return rc;
 }
 
-extern "C" int odevio_ode_rnn_fwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B,
-                                  int32_t P, float* poses, float* h_T, int32_t* stats, void* stream) {
-  ARGCHK(p && fused && ts && poses && h_T && B > 0 && P > 0, "odevio_ode_rnn_fwd: bad argument");
-  hipStream_t st = (hipStream_t)stream;
+static int ode_rnn_fwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
+                       float* poses, float* h_T, int32_t* stats, hipStream_t st) {
   int rc;
   if ((rc = ensure(p->out_seq, (size_t)B * P * p->F))) return rc;
   stage_mark(p, 4, st);
@@ -1087,6 +1168,16 @@ extern "C" int odevio_ode_rnn_fwd(odevio_plan* p, const float* fused, const floa
   stage_mark(p, 5, st);
   rc = regress(p, p->out_seq.p, B * P, poses, st);
   stage_mark(p, 6, st);
+  return rc;
+}
+
+extern "C" int odevio_ode_rnn_fwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B,
+                                  int32_t P, float* poses, float* h_T, int32_t* stats, void* stream) {
+  ARGCHK(p && fused && ts && poses && h_T && B > 0 && P > 0, "odevio_ode_rnn_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  const int rc = ode_rnn_fwd(p, fused, ts, hc_in, B, P, poses, h_T, stats, st);
+  post_status(p, st);
   return rc;
 }
 
@@ -1142,6 +1233,7 @@ static int forward_any(odevio_plan* p, const void* img, bool img_u8, const float
   ARGCHK(p && img && imu && ts && poses && h_T && B > 0 && S > 1, "odevio_forward: bad argument");
   if ((T - 1) / 10 != S - 1) return fail(ODEVIO_ERR_BAD_ARG, "imu length %d does not give %d frame pairs", T, S - 1);
   hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
   const int P = B * (S - 1), F = p->F;
   int rc;
   if ((rc = ensure(p->fcat, (size_t)P * F)) || (rc = ensure(p->fused, (size_t)P * F))) return rc;
@@ -1165,5 +1257,7 @@ static int forward_any(odevio_plan* p, const void* img, bool img_u8, const float
     if ((rc = fuse_from_cat(p, p->fcat.p, P, p->fused.p, st))) return rc;
     fused = p->fused.p;
   }
-  return odevio_ode_rnn_fwd(p, fused, ts, hc, B, S - 1, poses, h_T, stats, stream);
+  rc = ode_rnn_fwd(p, fused, ts, hc, B, S - 1, poses, h_T, stats, st);
+  post_status(p, st);
+  return rc;
 }

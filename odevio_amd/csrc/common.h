@@ -32,10 +32,40 @@ struct ConvArgs {
 //   in  : P2 layout [pixel][Cin/32][2][32] fp16;  w : [Cout][K-tile][2][32] fp16, K-tile = (channel group, tap), tap minor
 //   out : P2 (out_split = 1) or fp32 [M][Cout];  Cin % 32 == 0, Cout % 32 == 0
 #define ODEVIO_STATUS_RANGE 2   // word of the plan's status buffer raised when an activation leaves the fp16 range
+#define ODEVIO_STATUS_AUDIT 4   // audit build (make AUDIT=1): a kernel computed an address outside its buffers; word 5 = which
+#define ODEVIO_ZERO_PAGE_BYTES 256
+
+// Audit build (make AUDIT=1 -> libodevio_audit.so): every address the LDS-DMA / unchecked-load kernels compute is compared
+// with the extents of the buffer it must fall in BEFORE it is used; a violation raises the status word, records the
+// kernel, and the access is redirected (loads to the zero page, stores dropped), so the run never faults and the GPU
+// test-suite run against this library reports instead (tests/conftest.py).  The production
+// library compiles the checks out.
+#ifdef ODEVIO_AUDIT
+__device__ __forceinline__ bool audit_in(const void* p, size_t n, const void* lo, size_t bytes) {
+  const uintptr_t a = (uintptr_t)p, b = (uintptr_t)lo;
+  return a >= b && a + n <= b + bytes;
+}
+__device__ __forceinline__ void audit_flag(int* status, int kernel_id) {
+  atomicExch(status + ODEVIO_STATUS_AUDIT, 1);
+  atomicCAS(status + ODEVIO_STATUS_AUDIT + 1, 0, kernel_id);
+}
+// load source: must lie in [lo, lo+bytes) or in the zero page
+#define AUDIT_SRC(p, n, lo, bytes, zero, status, id) \
+  ((audit_in(p, n, lo, bytes) || audit_in(p, n, zero, ODEVIO_ZERO_PAGE_BYTES)) ? (p) : (audit_flag(status, id), (decltype(p))(zero)))
+#define AUDIT_DST_OK(p, n, lo, bytes, status, id) (audit_in(p, n, lo, bytes) ? true : (audit_flag(status, id), false))
+#else
+#define AUDIT_SRC(p, n, lo, bytes, zero, status, id) (p)
+#define AUDIT_DST_OK(p, n, lo, bytes, status, id) true
+#endif
+enum AuditKernel { AK_CONV_A = 1, AK_CONV_B = 2, AK_CONV_OUT = 3, AK_CONV_SLAB = 4, AK_CONV1_PATCH = 5, AK_CONV1_OUT = 6,
+                   AK_INGEST_SRC = 7, AK_INGEST_DST = 8, AK_REDUCE = 9 };
+
 struct ConvSplitArgs {
   const void* in;
   const void* w;
-  const void* zeros;    // >= 128 zero bytes: what the LDS-DMA reads for taps outside the image
+  const void* zeros;    // ODEVIO_ZERO_PAGE_BYTES zero bytes: what the LDS-DMA reads for taps outside the image
+  size_t in_bytes, w_bytes, out_bytes, partial_bytes;   // extents of in / w / out / partial: checked on the host at
+                                                        // every launch, and per access by the audit build
   const float* scale;   // [Cout] (BatchNorm scale with the weights' power-of-two pre-scale folded in)
   const float* shift;   // [Cout]
   void* out;
@@ -58,6 +88,8 @@ struct IngestArgs {
   const void* src;      // fp32 [frame][3][H][W], or uint8 [frame][H][W][3] (src_u8: normalised as byte / 255 - 0.5)
   int src_u8;
   void* planes;
+  size_t planes_bytes;
+  int* status;
   int n_frames, H, W, Hp, Wp;
 };
 
@@ -71,6 +103,7 @@ struct Conv1Args {
   const float* scale;   // [64]
   const float* shift;   // [64]
   void* out;            // NHWC [P][Ho][Wo][64] fp32, or the same pixels in P2 layout (out_split)
+  size_t planes_bytes, out_bytes;
   int out_split;
   int terms;            // 3 / 1 piece pairs per product (two-group kernel)
   int* status;
@@ -90,6 +123,17 @@ struct ImuArgs {
   float* out;           // [P][256*11] in (C,T) order
   int B, T, pairs_per_seq;
 };
+
+// hipFuncSetAttribute (dynamic LDS beyond 64 KB) is per device: true the first time the calling site runs on the
+// current device (one mask per call site)
+inline bool first_use_on_device(unsigned long long& mask) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const unsigned long long bit = 1ull << (d & 63);
+  const bool first = !(mask & bit);
+  mask |= bit;
+  return first;
+}
 
 void launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 void launch_conv1(const Conv1Args& a, int n_cu, hipStream_t st);

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
         const int xq = 8 * k - 4 + 4 * q;
         const bool ok = oky && (unsigned)xq < (unsigned)a.W;
         const f32x4 t = *reinterpret_cast<const f32x4*>(row + (ok ? xq : 0));   // unconditional load, clamped address
+                                                                                 // (row 0 / column 0 of the same plane)
 #pragma unroll
         for (int e = 0; e < 4; ++e) w12[4 * q + e] = ok ? t[e] : 0.f;
       }
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
       l[e] = (_Float16)(v8[e] - (float)h[e]);
     }
     _Float16* dst = reinterpret_cast<_Float16*>(a.planes) + ((plane * 2) * a.Hp + yp) * (size_t)a.Wp + 8 * k;
+    if (!AUDIT_DST_OK(dst, 16, a.planes, a.planes_bytes, a.status, AK_INGEST_DST) ||
+        !AUDIT_DST_OK(dst + (size_t)a.Hp * a.Wp, 16, a.planes, a.planes_bytes, a.status, AK_INGEST_DST)) continue;
     *reinterpret_cast<f16x8*>(dst) = h;
     *reinterpret_cast<f16x8*>(dst + (size_t)a.Hp * a.Wp) = l;
   }
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
   auto issue_patch_dma = [&](const unsigned char* corner, unsigned char* Pdst, int k) __attribute__((always_inline)) {
     const int g = H1_DMA_PER_WAVE * wave + k, p = g / 18, q = g - 18 * p;
     const unsigned char* src = d_off[k] >= 0 ? corner + d_off[k] : reinterpret_cast<const unsigned char*>(a.zeros);
+    src = AUDIT_SRC(src, 16, planes_b, a.planes_bytes, reinterpret_cast<const unsigned char*>(a.zeros), a.status, AK_CONV1_PATCH);
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Pdst + p * H1_PIECE_BYTES + 7 * q * H1_PW * 2), 16, 0, 0);
   };
   auto tile_corner = [&](int tile) __attribute__((always_inline)) {
@@ -285,7 +289,8 @@ __global__ __launch_bounds__(256) void conv1_f16x2_kernel(Conv1Args a) {
               const u32x2 hi = *reinterpret_cast<const u32x2*>(q + 8);
               if (px < px_valid) {
                 u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-                *reinterpret_cast<u32x4*>(outb + opix0 * 256 + o) = v;
+                if (AUDIT_DST_OK(outb + opix0 * 256 + o, 16, a.out, a.out_bytes, a.status, AK_CONV1_OUT))
+                  *reinterpret_cast<u32x4*>(outb + opix0 * 256 + o) = v;
               }
             }
           }
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
       for (int k = 0; k < H1_DMA_PER_WAVE; ++k) {
         const int g = H1_DMA_PER_WAVE * wave + k, p = g / 18, q = g - 18 * p;
         const unsigned char* src = d_off[k] >= 0 ? corner + d_off[k] : reinterpret_cast<const unsigned char*>(a.zeros);
+        src = AUDIT_SRC(src, 16, planes_b, a.planes_bytes, reinterpret_cast<const unsigned char*>(a.zeros), a.status, AK_CONV1_PATCH);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Pg + p * H1_PIECE_BYTES + 7 * q * H1_PW * 2), 16, 0, 0);
       }
     }
@@ -500,7 +506,8 @@ __global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
             const u32x2 hi = *reinterpret_cast<const u32x2*>(q + 8);
             if (px < px_valid) {
               u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-              *reinterpret_cast<u32x4*>(outb + opix0 * 256 + o) = v;
+              if (AUDIT_DST_OK(outb + opix0 * 256 + o, 16, a.out, a.out_bytes, a.status, AK_CONV1_OUT))
+                *reinterpret_cast<u32x4*>(outb + opix0 * 256 + o) = v;
             }
           }
         }
@@ -515,15 +522,19 @@ __global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
 }
 
 hipError_t launch_conv1_f16x2(const Conv1Args& a, int n_cu, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  // what the kernels assume (their patch DMAs are not bounds-checked): the ingested planes cover every tile's patch
+  if (a.Hp != 16 * a.tiles_y + 8 || a.Wp != 64 * a.tiles_x + 8 || a.tiles_y * H1_TH < a.Ho || a.tiles_x * H1_TW < a.Wo ||
+      a.planes_bytes < (size_t)a.B * a.S * 6 * a.Hp * a.Wp * 2 || a.n_tiles != a.B * (a.S - 1) * a.tiles_y * a.tiles_x ||
+      a.out_bytes < (size_t)a.B * (a.S - 1) * a.Ho * a.Wo * 256 || !a.planes || !a.zeros || !a.wt16 || !a.out)
+    return hipErrorInvalidValue;
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(attr_mask)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H1_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   (void)hipGetLastError();
   static const bool single = getenv("ODEVIO_CONV1_SINGLE") != nullptr;   // diagnostic: the one-group kernel

@@ -17,7 +17,7 @@
 // 32-channel group, 4 B per element like fp32.  Producers (conv1, this kernel, the split-K combine) split their fp32
 // result once in the epilogue.  Weights: [Cout][K-tile][2][32] with K-tile = (channel group, tap), tap minor.
 //
-// Tiling: 256 pixels x 128 output channels x 32 input channels per 512-thread workgroup (8 waves as 4 x 2, 64x64
+// Tiling (template on the channel tile BN): 256 pixels x 128 output channels x 32 input channels per 512-thread workgroup (8 waves as 4 x 2, 64x64
 // each: 4x4 MFMA 16x16x32 tiles x 3 piece pairs = 48 MFMAs per K-tile), one workgroup per CU.  The kernel is
 // power-limited (PMC: 1.76 GHz at 50 % MFMA busy, every staging/pipelining variant lands on the same time); the
 // 16x16x32 shape does the same flops 7 % faster than 32x32x16 here (6.30 vs 6.78 ms per forward).
@@ -31,23 +31,33 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define HBM_ 256            // pixels per tile
-#define HBN_ 128            // output channels per tile
 #define HROW 128            // bytes of one (row, K-tile) block: 2 pieces x 32 channels x 2 B
 #define HA_BYTES (HBM_ * HROW)
-#define HSTAGE ((HBM_ + HBN_) * HROW)   // 48 KB
-#define HSTAGES 3
-#define HBNW_ 256           // the wide variant's channel tile
-#define HSTAGEW ((HBM_ + HBNW_) * HROW)   // 64 KB
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Tile shapes.  BN = 128: three 48 KB stages (two tiles of DMA look-ahead).  BN = 256 ("wide", layers with
+// Cout % 256 == 0 whose tiles fill whole rounds of the chip): each wave 64 pixels x 128 channels, two 64 KB stages.
+// Why the wide tile exists: with one MFMA per product (TERMS = 1) the 256 x 128 kernel still needs 4.0 of its 6.3 ms -
+// the L2 -> LDS staging stream (52 GB per forward, ~13 TB/s) is a second ceiling right under the MFMA/power one, and a
+// 256 x 256 tile moves a third fewer bytes per flop.
+template <int BN> struct HTile {
+  static constexpr int STAGE = (HBM_ + BN) * HROW;        // bytes per stage
+  static constexpr int NSTAGE = BN == 128 ? 3 : 2;
+  static constexpr int LOOKAHEAD = NSTAGE - 1;            // tiles of DMA in flight beyond the one being multiplied
+  static constexpr int BDMA = BN / 64;                    // weight-row DMAs per wave and K-tile (8 rows each)
+  static constexpr int DMAS = 4 + BDMA;                   // DMAs per wave and K-tile
+  static constexpr int LDS = NSTAGE * STAGE;              // 144 KB / 128 KB
+};
+
 // TERMS = 3: the fp32-grade product described above.  TERMS = 1 (ODEVIO_CONV_MATH=f16, outside the fp32 parity claim):
 // only h_w h_x, i.e. plain fp16 operands (11-bit significands) with fp32 accumulation - the reduced-precision mode of
 // BASELINE configs[2]; same layout, same kernel, a third of the MFMAs.
-template <int TERMS>
+template <int TERMS, int BN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_kernel(ConvSplitArgs a) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // HSTAGES * HSTAGE = 144 KB
+  typedef HTile<BN> T;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // T::LDS bytes
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -65,11 +75,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   if (mt_idx * HBM_ >= a.M) return;
   const int m0 = mt_idx * HBM_;
-  const int n0 = nt_idx * HBN_;
+  const int n0 = nt_idx * BN;
 
   // ---- loader role.  One DMA instruction = 8 rows x 8 pieces of 16 B; lane l brings LDS slot (l & 7) of row
   // (l >> 3), which holds source piece slot ^ ((row >> 1) & 7).  Wave w stages pixel rows 32w .. 32w+31 (4 DMAs) and
-  // weight rows 16w .. 16w+15 (2 DMAs) of every K-tile.
+  // weight rows (BN/8)w .. (BN/8)w + BN/8 - 1 (BDMA DMAs) of every K-tile.
   const int groups = a.Cin >> 5;            // 32-channel groups per pixel
   const int taps = a.KH * a.KW;
   const int nk = taps * groups;             // K-tiles: (channel group, tap), tap minor
@@ -93,18 +103,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int wo = rem - ho * a.Wo;
       a_hi0[q] = ho * a.stride - a.pad;
       a_wi0[q] = wo * a.stride - a.pad;
+      // (hi0, wi0) may be negative: the pointer is only ever dereferenced with a tap offset that brings it inside the
+      // image (the `ok` test in issue_tile), never as it stands
       a_row[q] = in_b + ((ptrdiff_t)img * a.Hi * a.Wi + (ptrdiff_t)a_hi0[q] * a.Wi + a_wi0[q]) * px_bytes + a_poff[q];
     } else {
       a_row[q] = in_b;
-      a_hi0[q] = -(1 << 28);
+      a_hi0[q] = -(1 << 28);                // rows past M fail the `ok` test for every tap: zero page
       a_wi0[q] = -(1 << 28);
     }
   }
-  const unsigned char* b_row[2];
-  int b_poff[2];
+  const unsigned char* b_row[T::BDMA];
+  int b_poff[T::BDMA];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int r = 16 * wave + 8 * q + lr;   // row of the weight tile
+  for (int q = 0; q < T::BDMA; ++q) {
+    const int r = 8 * T::BDMA * wave + 8 * q + lr;   // row of the weight tile
     b_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
     const int n = n0 + r;
     b_row[q] = (n < a.Cout) ? w_b + (size_t)n * nk * HROW + b_poff[q] : nullptr;
@@ -144,27 +156,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   };
-  // 6 DMAs per wave and tile; the LDS destination is wave-uniform (+ lane * 16 by the hardware)
+  // T::DMAS DMAs per wave and tile; the LDS destination is wave-uniform (+ lane * 16 by the hardware)
   auto issue_tile = [&](int stage) __attribute__((always_inline)) {
-    unsigned char* dst = lds + stage * HSTAGE;
+    unsigned char* dst = lds + stage * T::STAGE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool ok = (unsigned)(a_hi0[q] + t_kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + t_kw) < (unsigned)a.Wi;
       const unsigned char* pa = ok ? a_row[q] + t_aoff : zero_b + a_poff[q];
+      pa = AUDIT_SRC(pa, 16, in_b, a.in_bytes, zero_b, a.status, AK_CONV_A);
       __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + (32 * wave + 8 * q) * HROW), 16, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < T::BDMA; ++q) {
       const unsigned char* pb = b_row[q] ? b_row[q] + t_boff : zero_b + b_poff[q];
-      __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + HA_BYTES + (16 * wave + 8 * q) * HROW), 16, 0, 0);
+      pb = AUDIT_SRC(pb, 16, w_b, a.w_bytes, zero_b, a.status, AK_CONV_B);
+      __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + HA_BYTES + (8 * T::BDMA * wave + 8 * q) * HROW), 16, 0, 0);
     }
   };
 
-  f32x4 acc[4][4];   // [pixel block of 16][channel block of 16]
+  constexpr int NB = BN / 32;   // 16-channel blocks per wave: 4 or 8
+  f32x4 acc[4][NB];   // [pixel block of 16][channel block of 16]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment reads.  16x16x32 MFMA: lane (fi, fh) holds row fi of a 16-row block, channels 8 fh .. 8 fh + 7 of the
   // 32-channel K-tile: source piece c = 4 * piece + fh, LDS slot c ^ ((row >> 1) & 7); block bases are multiples of 16
@@ -172,227 +187,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int fi = lane & 15, fh = lane >> 4;
   const int fsw = (fi >> 1) & 7;
   const int a_base = (wm * 64 + fi) * HROW;
-  const int b_base = HA_BYTES + (wn * 64 + fi) * HROW;
+  const int b_base = HA_BYTES + (wn * (BN / 2) + fi) * HROW;
 
   // D rows = output channels (weights are the MFMA's A operand), D columns = pixels: a lane ends up with 4
   // consecutive channels of one pixel per register group (one vector store each in the epilogue).
   auto multiply = [&](int stage) __attribute__((always_inline)) {
-    const unsigned char* Ab = lds + stage * HSTAGE + a_base;
-    const unsigned char* Bb = lds + stage * HSTAGE + b_base;
-    {
-      f16x8 xf[4][2], wf[4][2];   // [block][piece]
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int off = ((4 * p + fh) ^ fsw) * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          xf[i][p] = *reinterpret_cast<const f16x8*>(Ab + i * 16 * HROW + off);
-          wf[i][p] = *reinterpret_cast<const f16x8*>(Bb + i * 16 * HROW + off);
-        }
-      }
-      constexpr int PW[3] = {1, 0, 0};   // l_w h_x, h_w l_x, h_w h_x: small contributions first
-      constexpr int PX[3] = {0, 1, 0};
-      // accumulator-stationary order (the three piece pairs of one 16x16 block back to back, the pixel fragment
-      // reused across the four channel blocks): 2 % faster than piece-pair-major on this power-limited kernel
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int t = 3 - TERMS; t < 3; ++t)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n][PW[t]], xf[i][PX[t]], acc[i][n], 0, 0, 0);
-    }
-  };
-
-  const int ntile = kt_end - kt_begin;
-  // Prologue: tiles 0 and 1 in flight.  Past the end the walk stops and the same tile is fetched again (unused), so
-  // every wave always has exactly 6 DMAs per stage outstanding and the counted waits below stay exact.
-  issue_tile(0);
-  if (ntile > 1) next_tile();
-  issue_tile(1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int st_cur = 0, st_nxt = 2;   // stage holding tile j / stage to refill with tile j+2
-  for (int j = 0; j < ntile; ++j) {
-    if (j + 2 < ntile) next_tile();
-    issue_tile(st_nxt);                    // tile j+2 -> the stage tile j-1 was read from (everyone is past that barrier)
-    multiply(st_cur);
-    // tile j+1 has landed once all but the newest tile's DMAs are done; only then may anyone read it
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    st_nxt = st_cur;
-    st_cur = st_cur == 2 ? 0 : st_cur + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS
-
-  // ---- epilogue.  C/D map of the 16x16 MFMA: column (= pixel) = lane&15, row (= channel) = 4*(lane>>4) + r
-  bool range_bad = false;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fi;
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int nb4 = 0; nb4 < 4; ++nb4) {
-      const int n = n0 + wn * 64 + nb4 * 16 + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
-      if (n >= a.Cout) continue;
-      f32x4 v = acc[i][nb4];
-      if (a.splitk > 1) {
-        *reinterpret_cast<f32x4*>(a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
-      } else {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = v[e] * sc[e] + sh[e];
-          v[e] = x > 0.f ? x : x * a.slope;
-        }
-        if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
-        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ld_out + n) = v;
-      }
-    }
-  }
-  if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
-}
-
-// The same kernel with a 256 x 256 output tile (each wave 64 pixels x 128 channels) for layers with Cout % 256 == 0 and
-// enough tiles to fill the chip.  Why: with one MFMA per product (TERMS = 1) the 256 x 128 kernel still needs 4.0 of its
-// 6.3 ms - the L2 -> LDS staging stream (52 GB per forward, ~13 TB/s) is a second ceiling right under the MFMA/power one.
-// A 256 x 256 tile moves a third fewer bytes per flop.  Two 64 KB stages (the DMA of tile j+1 runs under the 96 MFMAs per
-// wave of tile j); the weight fragments are read in two halves to stay inside 256 registers.
-template <int TERMS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_wide_kernel(ConvSplitArgs a) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 * HSTAGEW = 128 KB
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: see conv_igemm_kernel
-  const int NT = gridDim.y;
-  int mt_idx = blockIdx.x, nt_idx = blockIdx.y;
-  if (a.xcd_map) {
-    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int chunk = gridDim.x >> 3;
-    mt_idx = xcd * chunk + slot / NT;
-    nt_idx = slot - (slot / NT) * NT;
-  }
-  if (mt_idx * HBM_ >= a.M) return;
-  const int m0 = mt_idx * HBM_;
-  const int n0 = nt_idx * HBNW_;
-
-  // ---- loader role.  One DMA instruction = 8 rows x 8 pieces of 16 B; lane l brings LDS slot (l & 7) of row
-  // (l >> 3), which holds source piece slot ^ ((row >> 1) & 7).  Wave w stages pixel rows 32w .. 32w+31 (4 DMAs) and
-  // weight rows 16w .. 16w+15 (2 DMAs) of every K-tile.
-  const int groups = a.Cin >> 5;            // 32-channel groups per pixel
-  const int taps = a.KH * a.KW;
-  const int nk = taps * groups;             // K-tiles: (channel group, tap), tap minor
-  const int px_bytes = groups * HROW;
-  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(a.in);
-  const unsigned char* w_b = reinterpret_cast<const unsigned char*>(a.w);
-  const int lr = lane >> 3, lslot = lane & 7;
-  const unsigned char* a_row[4];
-  int a_hi0[4], a_wi0[4];
-  int a_poff[4];                            // byte offset of this lane's source piece inside the 128-byte block
-  const int HoWo = a.Ho * a.Wo;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = 32 * wave + 8 * q + lr;   // row of the pixel tile
-    a_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
-    const int m = m0 + r;
-    if (m < a.M) {
-      const int img = m / HoWo;
-      const int rem = m - img * HoWo;
-      const int ho = rem / a.Wo;
-      const int wo = rem - ho * a.Wo;
-      a_hi0[q] = ho * a.stride - a.pad;
-      a_wi0[q] = wo * a.stride - a.pad;
-      a_row[q] = in_b + ((ptrdiff_t)img * a.Hi * a.Wi + (ptrdiff_t)a_hi0[q] * a.Wi + a_wi0[q]) * px_bytes + a_poff[q];
-    } else {
-      a_row[q] = in_b;
-      a_hi0[q] = -(1 << 28);
-      a_wi0[q] = -(1 << 28);
-    }
-  }
-  const unsigned char* b_row[4];
-  int b_poff[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = 32 * wave + 8 * q + lr;   // row of the weight tile
-    b_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
-    const int n = n0 + r;
-    b_row[q] = (n < a.Cout) ? w_b + (size_t)n * nk * HROW + b_poff[q] : nullptr;
-  }
-  const unsigned char* zero_b = reinterpret_cast<const unsigned char*>(a.zeros);
-
-  int kt_begin = 0, kt_end = nk;
-  if (a.splitk > 1) {
-    kt_begin = blockIdx.z * a.ktiles_per_split;
-    kt_end = min(nk, kt_begin + a.ktiles_per_split);
-  }
-
-  // K-tile walk (workgroup-uniform): channel group MAJOR, tap MINOR (the taps of one group re-read the same pixels
-  // shifted by one, back to back: L1/L2 hits), without divisions.
-  int t_kh = 0, t_kw = 0, t_g = 0, t_aoff = 0, t_boff = 0;
-  {
-    const int g = kt_begin / taps;
-    const int tap = kt_begin - g * taps;
-    t_g = g;
-    t_kh = tap / a.KW;
-    t_kw = tap - t_kh * a.KW;
-    t_aoff = (t_kh * a.Wi + t_kw) * px_bytes + g * HROW;
-    t_boff = kt_begin * HROW;
-  }
-  auto next_tile = [&]() {
-    ++t_kw;
-    t_aoff += px_bytes;
-    t_boff += HROW;
-    if (t_kw == a.KW) {
-      t_kw = 0;
-      ++t_kh;
-      t_aoff += (a.Wi - a.KW) * px_bytes;
-      if (t_kh == a.KH) {
-        t_kh = 0;
-        ++t_g;
-        t_aoff = t_g * HROW;
-      }
-    }
-  };
-  // 8 DMAs per wave and tile; the LDS destination is wave-uniform (+ lane * 16 by the hardware)
-  auto issue_tile = [&](int stage) __attribute__((always_inline)) {
-    unsigned char* dst = lds + stage * HSTAGEW;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bool ok = (unsigned)(a_hi0[q] + t_kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + t_kw) < (unsigned)a.Wi;
-      const unsigned char* pa = ok ? a_row[q] + t_aoff : zero_b + a_poff[q];
-      __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + (32 * wave + 8 * q) * HROW), 16, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const unsigned char* pb = b_row[q] ? b_row[q] + t_boff : zero_b + b_poff[q];
-      __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + HA_BYTES + (32 * wave + 8 * q) * HROW), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][8];   // [pixel block of 16][channel block of 16]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment reads.  16x16x32 MFMA: lane (fi, fh) holds row fi of a 16-row block, channels 8 fh .. 8 fh + 7 of the
-  // 32-channel K-tile: source piece c = 4 * piece + fh, LDS slot c ^ ((row >> 1) & 7); block bases are multiples of 16
-  // rows, so the permutation only depends on fi.  Conflict-free per ds_read_b128 lane group.
-  const int fi = lane & 15, fh = lane >> 4;
-  const int fsw = (fi >> 1) & 7;
-  const int a_base = (wm * 64 + fi) * HROW;
-  const int b_base = HA_BYTES + (wn * 128 + fi) * HROW;
-
-  // D rows = output channels (weights are the MFMA's A operand), D columns = pixels: a lane ends up with 4
-  // consecutive channels of one pixel per register group (one vector store each in the epilogue).
-  auto multiply = [&](int stage) __attribute__((always_inline)) {
-    const unsigned char* Ab = lds + stage * HSTAGEW + a_base;
-    const unsigned char* Bb = lds + stage * HSTAGEW + b_base;
+    const unsigned char* Ab = lds + stage * T::STAGE + a_base;
+    const unsigned char* Bb = lds + stage * T::STAGE + b_base;
     f16x8 xf[4][2];   // [block][piece]
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -402,8 +203,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     constexpr int PW[3] = {1, 0, 0};   // l_w h_x, h_w l_x, h_w h_x: small contributions first
     constexpr int PX[3] = {0, 1, 0};
+    // the weight fragments are read 64 channels at a time (the wide tile stays inside 256 registers that way);
+    // accumulator-stationary order (the three piece pairs of one 16x16 block back to back, the pixel fragment reused
+    // across the four channel blocks): 2 % faster than piece-pair-major on this power-limited kernel
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
+    for (int nh = 0; nh < NB / 4; ++nh) {
       f16x8 wf[4][2];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
@@ -422,18 +226,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 
   const int ntile = kt_end - kt_begin;
-  // Two stages: tile j is multiplied while the DMA of tile j+1 fills the other stage (which everybody finished reading
-  // before the barrier that ended step j-1).  Past the end the last tile is fetched again (unused): exact counts.
+  // Prologue: tiles 0 .. LOOKAHEAD-1 in flight.  Past the end the walk stops and the same tile is fetched again (unused),
+  // so every wave always has exactly DMAS DMAs per stage outstanding and the counted waits below stay exact.  The
+  // re-fetched tile is a tile of THIS workgroup's own K range: no look-ahead ever reads past a buffer.
   issue_tile(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (int j = 0; j < ntile; ++j) {
-    if (j + 1 < ntile) next_tile();
-    issue_tile((j + 1) & 1);
-    multiply(j & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int l = 1; l < T::LOOKAHEAD; ++l) {
+    if (l < ntile) next_tile();
+    issue_tile(l);
   }
+  // tile j+1 has landed once all but the newest LOOKAHEAD-1 tiles' DMAs are done; only then may anyone read it
+  if (T::LOOKAHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::DMAS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int st_cur = 0, st_nxt = T::LOOKAHEAD;   // stage holding tile j / stage to refill with tile j+LOOKAHEAD
+  for (int j = 0; j < ntile; ++j) {
+    if (j + T::LOOKAHEAD < ntile) next_tile();
+    issue_tile(st_nxt);                    // -> the stage tile j-1 was read from (everyone is past that barrier)
+    multiply(st_cur);
+    if (T::LOOKAHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::DMAS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    st_nxt = st_cur;
+    st_cur = st_cur + 1 == T::NSTAGE ? 0 : st_cur + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS
 
   // ---- epilogue.  C/D map of the 16x16 MFMA: column (= pixel) = lane&15, row (= channel) = 4*(lane>>4) + r
   bool range_bad = false;
@@ -442,12 +259,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int m = m0 + wm * 64 + i * 16 + fi;
     if (m >= a.M) continue;
 #pragma unroll
-    for (int nb4 = 0; nb4 < 8; ++nb4) {
-      const int n = n0 + wn * 128 + nb4 * 16 + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
+    for (int nb4 = 0; nb4 < NB; ++nb4) {
+      const int n = n0 + wn * (BN / 2) + nb4 * 16 + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
       if (n >= a.Cout) continue;
       f32x4 v = acc[i][nb4];
       if (a.splitk > 1) {
-        *reinterpret_cast<f32x4*>(a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n) = v;
+        float* dst = a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n;
+        if (AUDIT_DST_OK(dst, 16, a.partial, a.partial_bytes, a.status, AK_CONV_SLAB)) *reinterpret_cast<f32x4*>(dst) = v;
       } else {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
@@ -456,8 +274,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const float x = v[e] * sc[e] + sh[e];
           v[e] = x > 0.f ? x : x * a.slope;
         }
-        if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
-        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ld_out + n) = v;
+        if (a.out_split) {
+#ifdef ODEVIO_AUDIT
+          const unsigned char* q0 = reinterpret_cast<unsigned char*>(a.out) + ((size_t)m * (a.Cout >> 5) + (n >> 5)) * 128 + (n & 31) * 2;
+          if (!AUDIT_DST_OK(q0, 72, a.out, a.out_bytes, a.status, AK_CONV_OUT)) continue;
+#endif
+          range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
+        } else {
+          float* dst = reinterpret_cast<float*>(a.out) + (size_t)m * a.ld_out + n;
+          if (AUDIT_DST_OK(dst, 16, a.out, a.out_bytes, a.status, AK_CONV_OUT)) *reinterpret_cast<f32x4*>(dst) = v;
+        }
       }
     }
   }
@@ -488,31 +314,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16x2_kernel(ConvSplitArgs 
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 }
 
+template <int TERMS, int BN>
+static hipError_t launch_tile(const ConvSplitArgs& a, dim3 grid, hipStream_t st) {
+  static unsigned long long attr_mask = 0;   // the dynamic-LDS attribute is per device
+  if (first_use_on_device(attr_mask)) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<TERMS, BN>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, HTile<BN>::LDS);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((conv_f16x2_kernel<TERMS, BN>), grid, dim3(512), HTile<BN>::LDS, st, a);
+  return hipSuccess;
+}
+
+// Host-side check of what the kernel and its grid assume, at every launch (cheap; the kernel's DMAs are not
+// bounds-checked): layout divisibility, buffer extents, the zero page.
+static bool conv_args_consistent(const ConvSplitArgs& a) {
+  if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || a.KH < 1 || a.KW < 1 || a.stride < 1) return false;
+  if (a.wide && a.Cout % 256) return false;
+  if ((size_t)a.N * a.Ho * a.Wo != (size_t)a.M) return false;
+  if ((a.Hi + 2 * a.pad - a.KH) / a.stride + 1 != a.Ho || (a.Wi + 2 * a.pad - a.KW) / a.stride + 1 != a.Wo) return false;
+  const size_t nk = (size_t)a.KH * a.KW * (a.Cin / 32);
+  if (a.in_bytes < (size_t)a.N * a.Hi * a.Wi * a.Cin * 4) return false;          // P2: 4 bytes per element
+  if (a.w_bytes < (size_t)a.Cout * nk * HROW) return false;
+  if (a.splitk > 1) {
+    if (!a.partial || a.partial_bytes < (size_t)a.splitk * a.M * a.Cout * 4) return false;
+    if ((size_t)a.ktiles_per_split * (a.splitk - 1) >= nk) return false;         // every split owns at least one K-tile
+  }
+  const size_t out_need = a.out_split ? (size_t)a.M * a.Cout * 4 : ((size_t)(a.M - 1) * a.ld_out + a.Cout) * 4;
+  if (a.out_bytes < out_need || (!a.out_split && a.ld_out < a.Cout)) return false;
+  return a.in && a.w && a.zeros && a.out && a.scale && a.shift && a.status;
+}
+
 hipError_t launch_conv_f16x2(const ConvSplitArgs& a_in, hipStream_t st) {
   ConvSplitArgs a = a_in;
+  if (!conv_args_consistent(a)) return hipErrorInvalidValue;
   const int mt = (a.M + HBM_ - 1) / HBM_;
   a.xcd_map = mt >= 16;
-  const int bn = a.wide ? HBNW_ : HBN_;
+  const int bn = a.wide ? 256 : 128;
   dim3 grid(a.xcd_map ? (mt + 7) / 8 * 8 : mt, (a.Cout + bn - 1) / bn, a.splitk > 1 ? a.splitk : 1);
-  const size_t lds = a.wide ? (size_t)2 * HSTAGEW : (size_t)HSTAGES * HSTAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, HSTAGES * HSTAGE);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, HSTAGES * HSTAGE);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGEW);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGEW);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
   (void)hipGetLastError();
-  if (a.wide) {
-    if (a.terms == 1) hipLaunchKernelGGL(conv_f16x2_wide_kernel<1>, grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(conv_f16x2_wide_kernel<3>, grid, dim3(512), lds, st, a);
-  } else if (a.terms == 1) hipLaunchKernelGGL(conv_f16x2_kernel<1>, grid, dim3(512), lds, st, a);
-  else hipLaunchKernelGGL(conv_f16x2_kernel<3>, grid, dim3(512), lds, st, a);
+  hipError_t e;
+  if (a.wide) e = a.terms == 1 ? launch_tile<1, 256>(a, grid, st) : launch_tile<3, 256>(a, grid, st);
+  else e = a.terms == 1 ? launch_tile<1, 128>(a, grid, st) : launch_tile<3, 128>(a, grid, st);
+  if (e != hipSuccess) return e;
   if (a.splitk > 1) {
     const size_t total4 = (size_t)a.M * a.Cout / 4;
     int blocks = (int)((total4 + 255) / 256);

@@ -37,6 +37,7 @@
 //  * everything per element (bias, activation, publish, Runge-Kutta arithmetic, controller) runs on the
 //    OWNER thread of that element only: element (row r, local column cl) lives on thread cl*RT + r
 //    (at most 256 threads = waves 0..3), so the other twelve waves skip it instead of repeating it.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -667,17 +668,27 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
   }
 }
 
+// Cooperative launch: the all-gathers need all 256 workgroups resident at once.  A plain launch of the same grid has
+// the same residency on an idle device, but nothing checks it: if the grid does not fit (fewer CUs, a CU mask, a
+// register / LDS change that drops the occupancy to zero) the members spin until the 2 s timeout.
+// hipLaunchCooperativeKernel refuses such a grid at launch time (hipErrorCooperativeLaunchTooLarge) instead.
 template <int RT>
 static int launch_rt(const IntegArgs& a, size_t lds_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;   // per device
+  if (first_use_on_device(attr_mask)) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_kernel<RT>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
-  hipLaunchKernelGGL(integrator_kernel<RT>, dim3(INTEG_GROUPS * INTEG_MEMBERS), dim3(INTEG_THREADS), lds_bytes, st, a);
-  return 0;
+  static const bool plain = getenv("ODEVIO_PLAIN_LAUNCH") != nullptr;   // diagnostic: time the launch flavours
+  if (plain) {
+    hipLaunchKernelGGL(integrator_kernel<RT>, dim3(INTEG_GROUPS * INTEG_MEMBERS), dim3(INTEG_THREADS), lds_bytes, st, a);
+    return 0;
+  }
+  IntegArgs args = a;
+  void* params[] = {&args};
+  return (int)hipLaunchCooperativeKernel(reinterpret_cast<const void*>(integrator_kernel<RT>), dim3(INTEG_GROUPS * INTEG_MEMBERS),
+                                         dim3(INTEG_THREADS), params, (unsigned)lds_bytes, st);
 }
 
 int launch_integrator(const IntegArgs& a, int rt, size_t lds_bytes, void* stream) {

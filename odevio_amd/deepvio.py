@@ -129,7 +129,7 @@ class _PoseCDENet(nn.Module):
 
 
 class DeepVIO(nn.Module):
-    def __init__(self, opt, seed=None):
+    def __init__(self, opt, seed=None, state_dict=None):
         super().__init__()
         if opt.model_type == "ltc":
             raise NotImplementedError("LTC model not implemented yet")
@@ -152,9 +152,11 @@ class DeepVIO(nn.Module):
             self.Pose_net = _PoseNet(opt, with_ode=(opt.model_type == "ode-rnn"))
         self._plan = None
         self._plan_sig = None
+        self._warned_train = False
         self._lib = _lib.load()  # raises if the HIP library is missing: no silent fallback
         # the reference constructor leaves a random model behind (DeepVIO.py:43); ours is seeded
-        sd = weights.make_state_dict(opt, seed=getattr(opt, "seed", 0) if seed is None else seed)
+        # (or carries `state_dict`, which saves drawing weights that a caller would overwrite at once)
+        sd = state_dict if state_dict is not None else weights.make_state_dict(opt, seed=getattr(opt, "seed", 0) if seed is None else seed)
         self.load_state_dict(sd, strict=True)
         self.eval()
 
@@ -240,6 +242,13 @@ class DeepVIO(nn.Module):
     def forward(self, img, imu, timestamps, hc=None):
         """img [B,S,3,H,W], imu [B,10(S-1)+1(+tail),6], timestamps [B,S], hc None | [L,B,F] -> (poses [B,S-1,6], h_T [L,B,F])."""
         self._ensure_plan()
+        if self.training and self.opt.model_type != "cde" and not self._warned_train:
+            # the reference's training caller runs in train() (scripts/train_model.py:69); this forward has no autograd
+            # graph and uses BatchNorm running statistics: say so once instead of silently computing eval semantics
+            import warnings
+            warnings.warn("odevio_amd.DeepVIO.forward computes inference (eval-mode BatchNorm, no autograd graph) even in "
+                          "train(); use odevio_amd.train.OdeRnnFunction for gradients through the integrator", stacklevel=2)
+            self._warned_train = True
         if img.dtype == torch.uint8 and (self.opt.model_type == "cde" or self.opt.fuse_method == "hard"):
             raise ValueError("uint8 frames are supported for model_type ode-rnn / rnn with cat or soft fusion")
         if self.opt.model_type == "cde":

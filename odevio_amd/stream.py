@@ -126,6 +126,11 @@ class StreamTester:
     def test_paths(self, net, drives: Sequence[Drive]) -> List[np.ndarray]:
         """-> per drive the estimated relative poses [N-1, 6] (np.vstack of the windows, KITTI_eval.py:150-156)."""
         plans = [partition(d.frames.shape[0], self.seq_len) for d in drives]
+        check = getattr(net, "check", None)
+        if len(drives) > 1 and getattr(getattr(net, "opt", None), "model_type", "") == "cde":
+            # PoseCDE integrates every row over ROW 0's timestamps (PoseCDE.py:101): lock-stepping drives with
+            # different clocks would differ from walking each alone, as the reference does
+            raise ValueError("model_type 'cde' streams one drive at a time (PoseCDE.py:101 uses row 0's timestamps for the whole batch)")
         hc = [None] * len(drives)                       # per drive [L,1,F] on the device, None before the first window
         chunks = [[] for _ in drives]
         for step in range(max(len(p) for p in plans)):
@@ -142,6 +147,8 @@ class StreamTester:
                 ts = ts.to(self.device, torch.float32, non_blocking=True)
                 h_in = None if step == 0 else torch.cat([hc[k] for k in ks], dim=1)
                 pose, h_out = net(img, imu, ts, hc=h_in)
+                if check is not None:
+                    check()   # a failed forward (timeout, step budget, fp16x2 range) must not reach the metrics as garbage
                 for j, k in enumerate(ks):
                     hc[k] = h_out[:, j:j + 1].clone() if torch.is_tensor(h_out) else h_out
                     chunks[k].append(pose[j])
