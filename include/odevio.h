@@ -17,7 +17,8 @@
  *
  * Threading: a plan is not re-entrant (one forward at a time per plan); different plans are
  * independent.  No internal threads.  Nothing synchronises the stream except odevio_plan_create
- * (weight re-layout), odevio_reserve, odevio_check and odevio_cde_fwd (host-driven solver).
+ * (weight re-layout), odevio_reserve, odevio_check and the adaptive solver of odevio_cde_fwd (once per batch of
+ * enqueued step attempts, to read the device-side controller's `done` word).
  */
 #ifndef ODEVIO_H
 #define ODEVIO_H
@@ -139,11 +140,21 @@ int odevio_ode_steps(odevio_plan* plan, const float* y, const float* t0, const f
 int odevio_ode_rnn_fwd(odevio_plan* plan, const float* fused, const float* ts, const float* hc_in, int32_t B,
                        int32_t P, float* poses, float* h_T, int32_t* stats, void* stream);
 /* PoseCDE.forward after fusion (reference src/models/PoseCDE.py:94-103): obs [B,L,1+F] = [time | fused features] of every
- * observation so far (device), t_out = the output times ts[0,1:] (HOST doubles, n_out of them), z0_in NULL or a carried
- * [B,H] state -> poses [B,n_out,6], z0_out [B,H] (the reference returns the INITIAL state).  Host-driven solver
- * (torchdiffeq-style): synchronises `stream`.  stats_host = {steps, accepted} or NULL. */
+ * observation so far (device), t_out = the output times ts[0,1:] (HOST doubles, n_out of them, strictly ascending),
+ * z0_in NULL or a carried [B,H] state -> poses [B,n_out,6], z0_out [B,H] (the reference returns the INITIAL state).
+ * cdeint's controller (torchdiffeq dopri5: error norm, accept / reject, step size, knot clipping, dense output) runs on
+ * the DEVICE; the host enqueues step attempts ahead and reads the controller's `done` word once per batch of attempts
+ * (typically once per call), never per step.  The fixed-grid solvers (euler, rk4) do not synchronise at all.
+ * stats_host = {steps, accepted} or NULL. */
 int odevio_cde_fwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, const double* t_out_host, int32_t n_out,
                    const float* z0_in, float* poses, float* z0_out, int32_t* stats_host, void* stream);
+/* The Neural-CDE vector field for one piece of the control path (CDEFunc.forward, reference src/models/ODEFunc.py:76-83,
+ * contracted with dX/dt as torchcde's cdeint does): z [B,H], obs [B,L,1+F], seg = piece 0 .. 2L-3 of the rectilinear
+ * path (even: the time channel moves, odd: the features) -> out [B,H] = reshape(CDEFunc(z), [B,H,H+1]) . dX/dt(seg).
+ * The unit the adaptive solver calls 6 times per step; bench.py times it for the HBM roofline of the weight stream. */
+int odevio_cde_func(odevio_plan* plan, const float* z, const float* obs, int32_t B, int32_t L, int32_t seg, float* out,
+                    void* stream);
+
 /* DeepVIO.forward (DeepVIO.py:61-68): img [B,S,3,H,W], imu [B,T,6], ts [B,S], hc NULL or [L,B,F]
  * -> poses [B,S-1,6], h_T [L,B,F].  Asynchronous on `stream`; the inertial encoder runs on a stream owned by the plan,
  * forked from and joined back into `stream` with events (nothing for the caller to do). */

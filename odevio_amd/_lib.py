@@ -20,7 +20,7 @@ SYMBOLS = [
     "odevio_version", "odevio_last_error", "odevio_plan_create", "odevio_plan_destroy", "odevio_reserve",
     "odevio_check", "odevio_conv_block_fwd", "odevio_image_encoder_fwd", "odevio_imu_encoder_fwd", "odevio_fuse_fwd", "odevio_ode_func",
     "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
-    "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations",
+    "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func",
 ]
 
 
@@ -85,6 +85,7 @@ def load():
     lib.odevio_ode_steps.argtypes = [vp, fp, fp, fp, i32, i32, i32, fp, vp, vp]
     lib.odevio_ode_rnn_fwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_cde_fwd.argtypes = [vp, fp, i32, i32, vp, i32, fp, fp, fp, vp, vp]
+    lib.odevio_cde_func.argtypes = [vp, fp, fp, i32, i32, i32, fp, vp]
     lib.odevio_forward.argtypes = [vp, fp, fp, i32, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_forward_u8.argtypes = [vp, fp, fp, i32, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_profile_enable.argtypes = [vp, i32]

@@ -91,7 +91,9 @@ struct odevio_plan {
   // Neural-CDE path (model_type cde)
   CdeModel cde = {};
   float *cde_init_w = nullptr, *cde_init_b = nullptr;
-  DevBuf cde_ws;
+  DevBuf cde_ws, cde_fn_ws;
+  CdeCtl* cde_ctl_host = nullptr;   // pinned mirror of the device-side controller
+  int cde_hint_steps = 0;           // attempts the previous solve needed (first batch of the next one)
   // workspace (grown on demand)
   DevBuf actA, actB, imu_act, fcat, fused, out_seq, reg_hid, partial;
   std::vector<void*> owned;
@@ -251,13 +253,14 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
     }
   }
   if (p->status_host) (void)hipHostFree(p->status_host);
+  if (p->cde_ctl_host) (void)hipHostFree(p->cde_ctl_host);
   if (p->ev_status) (void)hipEventDestroy(p->ev_status);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->cde_ws, &p->pack_tmp, &p->ingest, &p->partial_side})
+                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
@@ -1187,16 +1190,22 @@ extern "C" int odevio_cde_fwd(odevio_plan* p, const float* obs, int32_t B, int32
   ARGCHK(p && obs && t_out_host && poses && z0_out && B > 0 && L > 1 && n_out > 0, "odevio_cde_fwd: bad argument");
   if (p->cfg.model_type != ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "plan is not a Neural-CDE plan");
   hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
   const int H = p->cde.H, C = p->cde.C, n = B * H;
   int rc;
-  const size_t need = (size_t)B * C + 24 * (size_t)n + 16 + (size_t)B * n_out * H;
+  // workspace: [ctl 512 B][t_out doubles][ha hb ytmp y y1][k 7n][interp 5n][z0][sol B*n_out*H]
+  const size_t head = (512 + (size_t)n_out * sizeof(double) + 15) / 16 * 4;   // floats, 16-byte aligned
+  const size_t need = head + 18 * (size_t)n + (size_t)B * n_out * H;
+  static_assert(sizeof(CdeCtl) <= 512, "CdeCtl outgrew its slot");
   if ((rc = ensure(p->cde_ws, need))) return rc;
+  if (!p->cde_ctl_host) HIPCHK(hipHostMalloc((void**)&p->cde_ctl_host, sizeof(CdeCtl), hipHostMallocDefault));
   float* q = p->cde_ws.p;
   CdeWork w;
-  w.scal = q; q += 16;
-  w.g = q; q += (size_t)B * C;
+  w.ctl = reinterpret_cast<CdeCtl*>(q);
+  w.t_out = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(q) + 512);
+  w.ctl_host = p->cde_ctl_host;
+  q += head;
   w.ha = q; q += n; w.hb = q; q += n; w.ytmp = q; q += n; w.y = q; q += n; w.y1 = q; q += n;
-  w.ymid = q; q += n; w.err = q; q += n; w.fnext = q; q += n;
   w.k = q; q += 7 * (size_t)n;
   w.interp = q; q += 5 * (size_t)n;
   float* z0 = q; q += n;
@@ -1206,11 +1215,37 @@ extern "C" int odevio_cde_fwd(odevio_plan* p, const float* obs, int32_t B, int32
   else cde_launch_linear(obs, L * C, p->cde_init_w, p->cde_init_b, z0, B, C, H, 0 /*tanh*/, st);
   HIPCHK(hipMemcpyAsync(z0_out, z0, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
   int stats[2] = {0, 0};
-  rc = cde_solve(p->cde, w, obs, B, L, t_out_host, n_out, z0, sol, stats, st);
+  p->cde.n_cu = p->n_cu;
+  rc = cde_solve(p->cde, w, obs, B, L, t_out_host, n_out, z0, sol, stats, p->cde_hint_steps, st);
   if (rc == ODEVIO_ERR_MAX_STEPS) return fail(rc, "cdeint: step budget exhausted");
+  if (rc == ODEVIO_ERR_BAD_ARG) return fail(rc, "cdeint: output times must be strictly ascending");
   if (rc) return fail(rc, "cdeint failed: %s", hipGetErrorString(hipGetLastError()));
+  p->cde_hint_steps = stats[0];
   if (stats_host) { stats_host[0] = stats[0]; stats_host[1] = stats[1]; }
-  return regress(p, sol, B * n_out, poses, st);
+  rc = regress(p, sol, B * n_out, poses, st);
+  post_status(p, st);
+  return rc;
+}
+
+extern "C" int odevio_cde_func(odevio_plan* p, const float* z, const float* obs, int32_t B, int32_t L, int32_t seg, float* out,
+                               void* stream) {
+  ARGCHK(p && z && obs && out && B > 0 && L > 1 && seg >= 0 && seg <= 2 * L - 3, "odevio_cde_func: bad argument");
+  if (p->cfg.model_type != ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "plan is not a Neural-CDE plan");
+  hipStream_t st = (hipStream_t)stream;
+  const int n = B * p->cde.H;
+  int rc;
+  if ((rc = ensure(p->cde_fn_ws, 2 * (size_t)n))) return rc;
+  p->cde.n_cu = p->n_cu;
+  const CdeWhen wh{nullptr, 0, seg, 0};
+  const float* x = z;
+  float* bufs[2] = {p->cde_fn_ws.p, p->cde_fn_ws.p + n};
+  for (int l = 0; l < p->cde.n_hidden; ++l) {
+    cde_launch_hidden(wh, x, p->cde.w[l], p->cde.b[l], bufs[l & 1], B, p->cde.H, p->cde.act, st);
+    x = bufs[l & 1];
+  }
+  if (cde_launch_last(p->cde, wh, x, obs, B, L, out, st)) return fail(ODEVIO_ERR_HIP, "CDE vector field launch failed");
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 static int forward_any(odevio_plan* p, const void* img, bool img_u8, const float* imu, int32_t T, const float* ts,

@@ -403,6 +403,16 @@ class DeepVIO(nn.Module):
                                             z0.data_ptr(), ctypes.cast(stats, ctypes.c_void_p), self._stream()))
         return (poses, z0, (int(stats[0]), int(stats[1]))) if return_stats else (poses, z0)
 
+    def cde_func(self, z, obs, seg):
+        """One evaluation of the Neural-CDE vector field on piece ``seg`` of the rectilinear control path built from
+        ``obs`` [B,L,1+F]: reshape(CDEFunc(z), [B,H,H+1]) @ dX/dt (reference ODEFunc.py:76-83 + torchcde's cdeint)."""
+        self._ensure_plan()
+        z, obs = self._dev(z, "z"), self._dev(obs, "obs")
+        out = torch.empty_like(z)
+        _lib.check(self._lib.odevio_cde_func(self._plan, z.data_ptr(), obs.data_ptr(), obs.shape[0], obs.shape[1], int(seg),
+                                             out.data_ptr(), self._stream()))
+        return out
+
     STAGES = ("conv1", "conv2_6", "visual_head", "imu_fuse", "integrator", "regressor")
 
     def profile_enable(self, on=True, depth=1):
