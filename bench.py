@@ -76,30 +76,56 @@ def conv_roofline(conv_tflops):
             "executed_mfma_peak": FP32_MFMA_PEAK_TFLOPS if CONV_MATH == "f32" else F16_MFMA_PEAK_TFLOPS,
             "note": f"fp32 operands as two fp16 pieces (22-bit significands), {MFMA_PER_PRODUCT} fp16 MFMAs per fp32 product, fp32 accumulate; "
                     f"peak = dense fp16 MFMA peak / {MFMA_PER_PRODUCT}; the fp32-input MFMA peak is 157.3; "
-                    "traffic = HBM bytes per forward of these launches from profiles/r01_pmc_traffic.json" if CONV_MATH != "f32" else
-                    "fp32-input MFMA; traffic = HBM bytes per forward from profiles/r01_pmc_traffic.json"}
+                    "traffic / pmc = rocprofv3 PMC passes of these sources committed under profiles/ (null when the committed profile is of other sources)" if CONV_MATH != "f32" else
+                    "fp32-input MFMA; traffic = HBM bytes per forward from the committed PMC passes of these sources"}
+
+
+def _profile_json(stem):
+    """Newest committed profiles/rNN_<stem>.json whose `source_sha` stamp matches the sources this run was built from
+    (tools/pmc_summary.py, tools/pmc_derive.py stamp them); an unstamped or stale profile is not quoted."""
+    import glob
+    from odevio_amd._lib import source_sha
+    sha = source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("source_sha") == sha:
+            return d, os.path.basename(path)
+    return None, None
 
 
 def pmc_derived(name):
-    """Utilisation figures of a kernel from the committed rocprofv3 PMC passes (tools/pmc_derive.py), or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{name}_derived.json")))
-        return {k: d[k] for k in ("clock_ghz", "mfma_busy", "lds_active", "lds_conflict", "ta_busy_avg", "wave_wait") if k in d}
-    except Exception:
+    """Utilisation figures of a kernel from the committed rocprofv3 PMC passes (tools/pmc_derive.py), or None when no
+    profile of the current sources is committed."""
+    d, _ = _profile_json(f"pmc_{name}_derived")
+    if d is None:
         return None
+    return {k: d[k] for k in ("clock_ghz", "mfma_busy", "lds_active", "lds_conflict", "ta_busy_avg", "wave_wait") if k in d}
 
 
-def pmc_traffic(kernel_key):
+def pmc_traffic_per_launch(kernel_key, stem):
+    """HBM bytes (fetched + written) per WORKING launch of one kernel from the committed PMC passes of these sources."""
+    d, _ = _profile_json(stem)
+    if d is None:
+        return None
+    hit = [v for k, v in d["kernels"].items() if k.startswith(kernel_key)]
+    if not hit or "fetch_bytes_per_working_dispatch" not in hit[0]:
+        return None
+    return int(hit[0]["fetch_bytes_per_working_dispatch"] + hit[0].get("write_bytes_per_working_dispatch", 0))
+
+
+def pmc_traffic(kernel_key, stem="pmc_traffic"):
     """HBM bytes per forward of one kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
     in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_summary.py).
-    Counters cannot be read from inside the timed run, so this is the last profiled value, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        ks = json.load(open(path))["kernels"]
-        hit = [v for k, v in ks.items() if k.startswith(kernel_key)]   # template instances / tile variants of one kernel
-        return int(sum(v["fetch_bytes"] + v["write_bytes"] for v in hit)) if hit else None
-    except Exception:
+    Counters cannot be read from inside the timed run, so this is the profiled value of THESE sources (stamp checked),
+    or None."""
+    d, _ = _profile_json(stem)
+    if d is None:
         return None
+    hit = [v for k, v in d["kernels"].items() if k.startswith(kernel_key)]   # template instances / tile variants of one kernel
+    return int(sum(v.get("fetch_bytes", 0) + v.get("write_bytes", 0) for v in hit)) if hit else None
 
 
 def f32_reference(opt, sd, img, imu, ts, steps=5):
@@ -175,6 +201,117 @@ def cpu_baseline(opt, sd, budget_s=20.0):
             "integrator_sample": f"{n} RK4 (3/8) steps of the [32,768] state through ODEFunc(768-512-512-512-768), best of 1/4/8/16/all threads"}
 
 
+def run_cde(args, rank, world, dist):
+    """BASELINE configs[4] on this harness: DeepVIO.forward with model_type cde (PoseCDE + CDEFunc, reference
+    src/models/PoseCDE.py:76-103), hidden 1024 = v_f_len 768 + i_f_len 256, dopri5 (the reference's default solver),
+    16 sequences x 11 frames per GPU, eval mode (raw timestamps).  The reference is fp32-only and its control path is
+    linear-rectilinear (PoseCDE.py:94), so that is what runs; the "cubic spline / bf16" wording of the config is BASELINE's."""
+    from odevio_amd import DeepVIO
+    Hc = args.cde_hidden
+    v = Hc * 3 // 4
+    opt = default_opt(model_type="cde", cde_hidden_dim=Hc, v_f_len=v, i_f_len=Hc - v, cde_solver="dopri5")
+    model = DeepVIO(opt, seed=0)
+    sd = model.state_dict() if (world == 1 and not args.no_cpu_baseline) else None
+    model = model.cuda().eval()
+    img, imu, ts = synth.batch(B, S, H, W, seed=100 + rank)
+    ts = ts + args.cde_t0
+    img, imu, ts = img.cuda(), imu.cuda(), ts.cuda()
+    gathered = torch.empty(world * B, S - 1, 6, device="cuda") if world > 1 else None
+
+    def step():
+        poses, z0 = model(img, imu, ts)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, poses)
+        return poses
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.check()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    model.check()
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        # ---- the dominant kernel: one vector-field evaluation on an odd piece = one pass over the [H*(H+1), H] fp32 last
+        # layer.  Timed with HIP events on the launch stream (torch's current stream is the one the library launches on).
+        fv, fi = model.image_encoder(img), model.imu_encoder(imu)
+        obs = torch.cat([ts[:, 1:, None], torch.cat([fv, fi], -1)], -1).contiguous()
+        z = torch.tanh(torch.randn(B, Hc, generator=torch.Generator().manual_seed(0))).cuda()
+        _, _, (n_steps, n_acc) = model.pose_cde(fv, fi, ts, None, return_stats=True)
+        n_ev = 20
+        for _ in range(3):
+            model.cde_func(z, obs, 1)
+        model.profile_enable(True)
+        ev_ms = 0.0
+        for _ in range(n_ev):          # HIP events on the launch stream around the weight-stream kernel of each evaluation
+            model.cde_func(z, obs, 1)
+            ev_ms += model.cde_last_ms() / n_ev
+        model.profile_enable(False)
+        w_bytes = Hc * (Hc + 1) * Hc * 4 + Hc * (Hc + 1) * 4 + 2 * B * Hc * 4     # last-layer weights + bias + x in + f out
+        gbs = w_bytes / (ev_ms * 1e-3) / 1e9
+        out = {
+            "metric": METRIC, "value": round(world * B * S * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DeepVIO.forward, model_type cde: {B} sequences x {S} frames 256x512 per GPU, PoseCDE hidden {Hc} "
+                                   f"(CDEFunc {Hc}-{Hc}-{Hc}-{Hc}-{Hc * (Hc + 1)}), dopri5 rtol 1e-4 atol 1e-6, eval mode, window "
+                                   f"t = {args.cde_t0:.2f} .. {args.cde_t0 + 1.0:.2f} s (piece 1 of the rectilinear control path: every feature "
+                                   "channel moves, each evaluation streams the whole last layer), fp32 (BASELINE configs[4] shape)",
+                       "sequences_per_gpu": B, "seq_len": S, "cde_solver": "dopri5", "sharding": f"sequences x{world}"},
+            "solver": {"steps_attempted": n_steps, "steps_accepted": n_acc,
+                       "note": "one step size for the whole batch (torchdiffeq); controller on the device, the host reads `done` once per batch of attempts"},
+            "roofline": {"kernel": f"cde_stream_kernel<{Hc}> (CDEFunc last layer + tanh + contraction with dX/dt)", "bound": "hbm",
+                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic_per_launch("cde_stream_kernel", "pmc_cde_traffic"),
+                         "us_per_launch": round(ev_ms * 1e3, 1), "bytes_per_launch": w_bytes,
+                         "note": "algorithmic bytes = the fp32 last layer [H*(H+1), H] + bias + x + f, once per evaluation; time = HIP events "
+                                 f"around that launch, mean of {n_ev} evaluations; 6.29 TB/s is the measured copy peak; traffic = PMC bytes per working launch "
+                                 "of these sources (profiles/rNN_pmc_cde_traffic.json) or null"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cde_cpu_baseline(opt, sd, obs.cpu(), z.cpu(), n_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cde_cpu_baseline(opt, sd, obs, z, n_steps, budget_s=20.0):
+    """The oracle's vector field (CDEFunc + contraction, the unit dopri5 calls 6 times per step + 2 for the initial step)
+    timed on this box's cores on a bounded sample; frames/s = what the whole window would take at that rate (encoder not
+    included: it is < 2 % of the CPU time here)."""
+    from oracle import odevio_oracle as oc
+    sdc = oc._sd(sd, torch.float32)
+    coeffs = oc.rectilinear_coeffs(obs)
+    f = oc.cde_field(sdc, opt, coeffs, torch.float32)
+    with torch.no_grad():
+        f(1.5, z)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            f(1.5, z)
+            reps += 1
+            if time.perf_counter() - t0 > budget_s or reps >= 10:
+                break
+        t_eval = (time.perf_counter() - t0) / reps
+    n_evals = 6 * n_steps + 2
+    return {"value": B * S / (n_evals * t_eval), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle CDE vector field (hidden {opt.cde_hidden_dim}, {B} rows), {reps} evaluations of {t_eval:.3f} s each; "
+                      f"window = {n_evals} evaluations ({n_steps} dopri5 steps)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +320,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-reference", action="store_true", help="skip the short run with the fp32-input MFMA encoder")
     # not part of the driver's contract: other BASELINE configurations on the same harness (configs[2]: dopri5, 50 % drop)
+    ap.add_argument("--model", default="ode-rnn", choices=["ode-rnn", "cde"],
+                    help="cde: BASELINE configs[4] (PoseCDE, hidden 1024) on the same harness, with the roofline of its weight stream")
+    ap.add_argument("--cde-hidden", type=int, default=1024)
+    ap.add_argument("--cde-t0", type=float, default=1.0,
+                    help="first timestamp of the synthetic window (eval mode = raw time): 1.0 puts the window on piece 1 of the control "
+                         "path, where dX/dt moves every feature channel and each evaluation streams the whole last layer")
     ap.add_argument("--ode-solver", default="rk4")
     ap.add_argument("--drop", type=float, default=0.0, help="frame-drop probability of the synthetic timestamps")
     args = ap.parse_args()
@@ -210,6 +353,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+
+    if args.model == "cde":
+        return run_cde(args, rank, world, dist)
 
     from odevio_amd import DeepVIO
     opt = default_opt(ode_solver=args.ode_solver)

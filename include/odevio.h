@@ -148,12 +148,34 @@ int odevio_ode_rnn_fwd(odevio_plan* plan, const float* fused, const float* ts, c
  * stats_host = {steps, accepted} or NULL. */
 int odevio_cde_fwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, const double* t_out_host, int32_t n_out,
                    const float* z0_in, float* poses, float* z0_out, int32_t* stats_host, void* stream);
+/* Backward of odevio_ode_rnn_fwd: what `loss.backward()` reaches below the encoders in the reference's training step
+ * (scripts/train_model.py:69-78; autograd through torchode's AutoDiffAdjoint = backpropagation through the solver's own
+ * operations, "discretise-then-optimise").  Inputs as in the forward plus grad_poses [B,P,6] and grad_hT [L,B,F] or NULL;
+ * outputs grad_fused [B,P,F] (or NULL), grad_hc [L,B,F] (or NULL; needs hc_in) and the weight gradients listed in
+ * `grads`: name = the reference state_dict key (Pose_net.ode_func.net.{0,2,..}.{weight,bias},
+ * Pose_net.rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l{k}, Pose_net.regressor.{0,2}.{weight,bias}), data = DEVICE pointer
+ * the gradient is WRITTEN to (same shape as the parameter), numel checked.  The forward is recomputed inside (nothing is
+ * kept from odevio_ode_rnn_fwd).  Built so far: fixed-step solvers (rk4, rk4_classic, any ode_substeps) and tanh
+ * nn.RNN; ODEVIO_ERR_UNSUPPORTED otherwise (adaptive solvers, nn.GRU, the Neural-CDE path). */
+int odevio_ode_rnn_bwd(odevio_plan* plan, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
+                       const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
+                       const odevio_tensor* grads, int32_t n_grads, void* stream);
+/* The reference's training loss and its gradient (scripts/train_model.py:72-77): loss3 (device, 3 floats) =
+ * {100 * angle_loss + translation_loss, angle_loss, translation_loss} with MSE over the first / last three pose columns of
+ * n_rows = B*P rows; grad_poses [n_rows,6] = d loss3[0] / d poses, or NULL. */
+int odevio_pose_loss(const float* poses, const float* gts, int32_t n_rows, float* loss3, float* grad_poses, void* stream);
+
 /* The Neural-CDE vector field for one piece of the control path (CDEFunc.forward, reference src/models/ODEFunc.py:76-83,
  * contracted with dX/dt as torchcde's cdeint does): z [B,H], obs [B,L,1+F], seg = piece 0 .. 2L-3 of the rectilinear
  * path (even: the time channel moves, odd: the features) -> out [B,H] = reshape(CDEFunc(z), [B,H,H+1]) . dX/dt(seg).
  * The unit the adaptive solver calls 6 times per step; bench.py times it for the HBM roofline of the weight stream. */
 int odevio_cde_func(odevio_plan* plan, const float* z, const float* obs, int32_t B, int32_t L, int32_t seg, float* out,
                     void* stream);
+
+/* Measurement only: duration (ms, HIP events on the launch stream) of the LAST LAYER of the most recent odevio_cde_func
+ * call - on an odd piece that is the weight-stream kernel alone - while the stage timers are on (odevio_profile_enable).
+ * Waits for that call.  bench.py --model cde prices it against the HBM roofline. */
+int odevio_cde_last_ms(odevio_plan* plan, float* ms_out);
 
 /* DeepVIO.forward (DeepVIO.py:61-68): img [B,S,3,H,W], imu [B,T,6], ts [B,S], hc NULL or [L,B,F]
  * -> poses [B,S-1,6], h_T [L,B,F].  Asynchronous on `stream`; the inertial encoder runs on a stream owned by the plan,

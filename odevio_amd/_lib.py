@@ -20,8 +20,23 @@ SYMBOLS = [
     "odevio_version", "odevio_last_error", "odevio_plan_create", "odevio_plan_destroy", "odevio_reserve",
     "odevio_check", "odevio_conv_block_fwd", "odevio_image_encoder_fwd", "odevio_imu_encoder_fwd", "odevio_fuse_fwd", "odevio_ode_func",
     "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
-    "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func",
+    "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func", "odevio_cde_last_ms",
+    "odevio_ode_rnn_bwd", "odevio_pose_loss",
 ]
+
+
+def source_sha():
+    """sha256 (first 16 hex digits) of the library's sources (csrc/*.hip, *.h, include/odevio.h): profiles are stamped with
+    it, and bench.py only quotes a committed PMC figure when the stamp matches the sources it runs."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "odevio.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 class OdevioConfig(ctypes.Structure):
@@ -85,6 +100,9 @@ def load():
     lib.odevio_ode_steps.argtypes = [vp, fp, fp, fp, i32, i32, i32, fp, vp, vp]
     lib.odevio_ode_rnn_fwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_cde_fwd.argtypes = [vp, fp, i32, i32, vp, i32, fp, fp, fp, vp, vp]
+    lib.odevio_cde_last_ms.argtypes = [vp, fp]
+    lib.odevio_ode_rnn_bwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
+    lib.odevio_pose_loss.argtypes = [fp, fp, i32, fp, fp, vp]
     lib.odevio_cde_func.argtypes = [vp, fp, fp, i32, i32, i32, fp, vp]
     lib.odevio_forward.argtypes = [vp, fp, fp, i32, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_forward_u8.argtypes = [vp, fp, fp, i32, fp, fp, i32, i32, fp, fp, vp, vp]

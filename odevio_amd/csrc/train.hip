@@ -1,0 +1,415 @@
+// Backward of the ODE-RNN pose path (first slice of SURVEY.md section 8f-3): gradients of a loss on the poses through
+// the regressor, the nn.RNN stack and the Runge-Kutta solve of every interval, down to the fused features, the
+// carried hidden state and every weight of ODEFunc / RNN / regressor - what `loss.backward()` reaches below the
+// encoders in the reference's training step (scripts/train_model.py:69-78: poses -> 100 * MSE(angles) + MSE(trans) ->
+// autograd through torchode's AutoDiffAdjoint = backpropagation through the solver's own operations).
+//
+// Discretise-then-optimise: the backward differentiates exactly the arithmetic the forward performs (same tableau,
+// same steps), so the gradients are the gradients of the computed poses, not of the continuous ODE.
+//
+// Structure (correctness first; the forward's persistent kernel has no backward twin yet):
+//   1. TAPE: the forward is recomputed with plain launches (skinny MFMA GEMMs + element-wise kernels), writing every
+//      layer input / output of every stage evaluation into row-stacked matrices act[l] [M, dims[l]] with
+//      M = intervals x sub-steps x stages x rows, and the RNN cell inputs / outputs per layer;
+//   2. REVERSE SWEEP interval by interval: RNN cell backward, then the adjoint of every RK step (stage by stage, last
+//      to first), writing the pre-activation gradients into delta[l] [M, dims[l+1]];
+//   3. WEIGHT GRADIENTS as ONE GEMM per weight: dW_l = delta[l]^T act[l] (contraction over all M rows at once: the
+//      rank-R updates of a step-by-step formulation become a single [N, M] x [M, K] product), biases = column sums.
+// Supported now: fixed-step solvers (rk4 = 3/8 rule, rk4_classic; any ode_substeps), tanh nn.RNN, every ODEFunc
+// activation, cat / soft fusion handled by the caller (the gradient is returned w.r.t. the FUSED features).
+// Adaptive solvers (replaying the accepted step sequence of the forward) and nn.GRU: next.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/odevio.h"
+#include "common.h"
+#include "train.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny GEMMs on the fp32 MFMA (v_mfma_f32_16x16x4_f32: an exact fmaf chain).  One 4-wave workgroup per 16 x 16 output
+// tile; the waves take the 16-wide k-steps round robin and combine through LDS in wave order (deterministic).
+//   NT: out[m][n] (+)= sum_k A[m * lda + k] * W[n * ldw + k] (+ bias[n])          K % 16 == 0
+//   TN: out[n][k] (+)= sum_m D[m * ldd + n] * A[m * lda + k]                      (weight gradients: contraction over rows)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
+                                                      int accumulate) {
+  __shared__ float red[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  // MFMA A operand = W rows (D rows = output columns n), B operand = A rows (D columns = m)
+  const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * q;
+  const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 16 * wave; k < K; k += 64) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k);
+    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];   // [n local][m local]
+  __syncthreads();
+  const int nl = tid >> 4, ml = tid & 15;
+  const int n = n0 + nl, m = m0 + ml;
+  if (n < N && m < M) {
+    float v = (red[0][nl][ml] + red[1][nl][ml]) + (red[2][nl][ml] + red[3][nl][ml]);
+    if (bias) v += bias[n];
+    float* o = out + (size_t)m * ldo + n;
+    *o = accumulate ? *o + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ A, int lda,
+                                                      float* __restrict__ out, int ldo, int M, int N, int K, int accumulate) {
+  __shared__ float red[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  const int nn = min(n0 + r, N - 1), kk = min(k0 + r, K - 1);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // contraction over rows m: MFMA j of a 16-row step uses rows m = 16 s + 4 q + j
+  for (int mb = 16 * wave; mb < M; mb += 64) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + 4 * q + j;
+      const float dv = m < M ? D[(size_t)m * ldd + nn] : 0.f;
+      const float av = m < M ? A[(size_t)m * lda + kk] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, av, acc, 0, 0, 0);   // D rows = n, D columns = k
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];   // [n local][k local]
+  __syncthreads();
+  const int nl = tid >> 4, kl = tid & 15;
+  const int n = n0 + nl, k = k0 + kl;
+  if (n < N && k < K) {
+    const float v = (red[0][nl][kl] + red[1][nl][kl]) + (red[2][nl][kl] + red[3][nl][kl]);
+    float* o = out + (size_t)n * ldo + k;
+    *o = accumulate ? *o + v : v;
+  }
+}
+
+static void gemm_nt(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N,
+                    int K, bool accumulate = false) {
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K,
+                     accumulate ? 1 : 0);
+}
+static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K,
+                    bool accumulate = false) {
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((K + 15) / 16, (N + 15) / 16), dim3(256), 0, st, D, ldd, A, lda, out, ldo, M, N, K, accumulate ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// element-wise kernels
+// ---------------------------------------------------------------------------------------------------------------------
+#define EW_GRID(n) dim3((unsigned)std::min<size_t>(((size_t)(n) + 255) / 256, 4096)), dim3(256)
+#define EW_LOOP(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); i += (size_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float tr_act(float v, int act) {   // ODEFunc.py:23-36 (LeakyReLU default slope 0.01)
+  switch (act) {
+    case 0: return tanhf(v);
+    case 1: return fmaxf(v, 0.f);
+    case 2: return v > 0.f ? v : 0.01f * v;
+    default: return v > 20.f ? v : log1pf(expf(v));
+  }
+}
+// derivative expressed through the activation's OUTPUT a (what the tape keeps)
+__device__ __forceinline__ float tr_act_grad(float a, int act) {
+  switch (act) {
+    case 0: return 1.f - a * a;
+    case 1: return a > 0.f ? 1.f : 0.f;
+    case 2: return a > 0.f ? 1.f : 0.01f;
+    default: return a > 20.f ? 1.f : -expm1f(-a);   // softplus: sigmoid(z) = 1 - exp(-a)
+  }
+}
+
+__global__ void act_kernel(float* x, size_t n, int act) { EW_LOOP(i, n) x[i] = tr_act(x[i], act); }
+
+// dt[i][r] = (ts[b][i+1] - ts[b][i]) / nsub with b = r % B (the relative shift of PoseODERNN.py:100 cancels in the difference)
+__global__ void dt_rows_kernel(const float* __restrict__ ts, float* __restrict__ dt, int B, int P, int R, int nsub) {
+  EW_LOOP(i, (size_t)P * R) {
+    const int it = (int)(i / R), b = (int)(i % R) % B;
+    const float* tr = ts + (size_t)b * (P + 1);
+    dt[i] = (tr[it + 1] - tr[it]) / (float)nsub;
+  }
+}
+
+// X_s = Y + dt[r] * sum_j a[j] K_j   (K_j = kbase + j * kstride; same association as the forward kernels and the oracle)
+struct StageCoef { float c[8]; int n; };
+__global__ void stage_input_kernel(float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ kbase, size_t kstride,
+                                   StageCoef a, const float* __restrict__ dt, int R, int F) {
+  EW_LOOP(i, (size_t)R * F) {
+    const int r = (int)(i / F);
+    float acc = 0.f;
+    bool first = true;
+    for (int j = 0; j < a.n; ++j) {
+      if (a.c[j] == 0.f) continue;
+      const float term = kbase[j * kstride + i] * a.c[j];
+      acc = first ? term : acc + term;
+      first = false;
+    }
+    X[i] = first ? Y[i] : Y[i] + dt[r] * acc;
+  }
+}
+
+// rows of a [B][P][F] tensor <-> rows of an interval-major [P*B][F] matrix
+__global__ void gather_interval_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int P, int F, int it) {
+  EW_LOOP(i, (size_t)B * F) {
+    const int b = (int)(i / F), c = (int)(i % F);
+    dst[i] = src[((size_t)b * P + it) * F + c];
+  }
+}
+__global__ void scatter_interval_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int P, int F, int it) {
+  EW_LOOP(i, (size_t)B * F) {
+    const int b = (int)(i / F), c = (int)(i % F);
+    dst[((size_t)b * P + it) * F + c] = src[i];
+  }
+}
+
+// tanh RNN cell: hn = tanh(gi + gh)
+__global__ void rnn_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh, float* __restrict__ hn, float* __restrict__ ynew, size_t n) {
+  EW_LOOP(i, n) {
+    const float v = tanhf(gi[i] + gh[i]);
+    hn[i] = v;
+    ynew[i] = v;
+  }
+}
+// delta = (g [+ g2]) * (1 - hn^2)
+__global__ void rnn_cell_bwd_kernel(const float* __restrict__ g, const float* __restrict__ g2, const float* __restrict__ hn,
+                                    float* __restrict__ delta, size_t n) {
+  EW_LOOP(i, n) {
+    const float gg = g[i] + (g2 ? g2[i] : 0.f);
+    delta[i] = gg * (1.f - hn[i] * hn[i]);
+  }
+}
+__global__ void add_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n) { EW_LOOP(i, n) x[i] += y[i]; }
+// delta = g * act'(a)
+__global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a, float* __restrict__ delta, size_t n, int act) {
+  EW_LOOP(i, n) delta[i] = g[i] * tr_act_grad(a[i], act);
+}
+// start of a step's adjoint: lamK_s = dt[r] * b_s * lam
+__global__ void step_adjoint_init_kernel(const float* __restrict__ lam, float* __restrict__ lamK, size_t kstride, StageCoef b,
+                                         const float* __restrict__ dt, int R, int F) {
+  EW_LOOP(i, (size_t)R * F) {
+    const int r = (int)(i / F);
+    for (int s = 0; s < b.n; ++s) lamK[s * kstride + i] = dt[r] * b.c[s] * lam[i];
+  }
+}
+// after stage s: lam += gX;  lamK_j += dt[r] * a_sj * gX for j < s
+__global__ void stage_adjoint_kernel(float* __restrict__ lam, float* __restrict__ lamK, size_t kstride, const float* __restrict__ gX,
+                                     StageCoef a, const float* __restrict__ dt, int R, int F) {
+  EW_LOOP(i, (size_t)R * F) {
+    const int r = (int)(i / F);
+    const float g = gX[i];
+    lam[i] += g;
+    for (int j = 0; j < a.n; ++j)
+      if (a.c[j] != 0.f) lamK[j * kstride + i] += dt[r] * a.c[j] * g;
+  }
+}
+// column sums of a [M][N] matrix (bias gradients); one thread per column, rows in order (deterministic)
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
+  EW_LOOP(n, N) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += x[(size_t)m * N + n];
+    out[n] = s;
+  }
+}
+// regressor.2 backward: dhid[m][k] = (sum_n dp[m][n] W2[n][k]) * leaky'(hid[m][k])   (6 outputs: no GEMM needed)
+__global__ void reg2_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ W2, const float* __restrict__ hid,
+                                float* __restrict__ dhid, int M) {
+  EW_LOOP(i, (size_t)M * 128) {
+    const int m = (int)(i / 128), k = (int)(i % 128);
+    float s = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) s += dp[(size_t)m * 6 + n] * W2[n * 128 + k];
+    dhid[i] = s * (hid[i] > 0.f ? 1.f : 0.1f);
+  }
+}
+__global__ void leaky_kernel(float* x, size_t n, float slope) { EW_LOOP(i, n) x[i] = x[i] > 0.f ? x[i] : slope * x[i]; }
+
+// loss = 100 * mean((p - g)^2 over the 3 angle columns) + mean((p - g)^2 over the 3 translation columns)
+// (scripts/train_model.py:72-77) and its gradient w.r.t. the poses; one workgroup, deterministic order.
+__global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict__ poses, const float* __restrict__ gts, int M,
+                                                        float* __restrict__ loss3, float* __restrict__ grad) {
+  __shared__ double sa[256], st[256];
+  double a = 0.0, t = 0.0;
+  const double inv = 1.0 / (3.0 * (double)M);
+  for (int i = threadIdx.x; i < M * 6; i += 256) {
+    const int c = i % 6;
+    const float d = poses[i] - gts[i];
+    if (c < 3) a += (double)d * d; else t += (double)d * d;
+    if (grad) grad[i] = (float)((c < 3 ? 200.0 : 2.0) * inv * (double)d);
+  }
+  sa[threadIdx.x] = a; st[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; st[threadIdx.x] += st[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float al = (float)(sa[0] * inv), tl = (float)(st[0] * inv);
+    loss3[0] = 100.f * al + tl; loss3[1] = al; loss3[2] = tl;
+  }
+}
+
+int train_pose_loss(const float* poses, const float* gts, int M, float* loss3, float* grad, hipStream_t st) {
+  hipLaunchKernelGGL(pose_loss_kernel, dim3(1), dim3(256), 0, st, poses, gts, M, loss3, grad);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+size_t train_workspace_floats(const TrainModel& m, int B, int P) {
+  const int R = m.L * B, S = m.stages;
+  const size_t M = (size_t)P * m.nsub * S * R, MB = (size_t)P * B;
+  size_t n = 0;
+  for (int l = 0; l <= m.nlin; ++l) n += M * m.dims[l];          // act
+  for (int l = 0; l < m.nlin; ++l) n += M * m.dims[l + 1];       // delta
+  n += ((size_t)P * R + 3) / 4 * 4;                              // dt (kept 16-byte aligned: the GEMM operands behind it are read as float4)
+  n += 3 * (size_t)R * m.F;                                      // Y, lam, gX
+  n += 8 * (size_t)R * m.F;                                      // lamK
+  n += (size_t)R * std::max(m.F, m.H);                           // scratch g
+  n += (size_t)m.L * MB * m.F * 4;                               // rnn_in, rnn_hp, rnn_out, rnn_delta
+  n += 4 * (size_t)B * m.F;                                      // gi, gh, dinp, dhp
+  n += MB * 128 * 2 + (MB * 6 + 3) / 4 * 4 + MB * m.F;           // hid, dhid, dposes (interval-major), dout
+  return n;
+}
+
+int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const float* ts, const float* hc, int B, int P,
+                      const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc, const TrainGrads& g,
+                      hipStream_t st) {
+  const int L = m.L, F = m.F, R = L * B, S = m.stages, nl = m.nlin;
+  const size_t M = (size_t)P * m.nsub * S * R, MB = (size_t)P * B, RF = (size_t)R * F;
+  // ---- carve the workspace
+  float* q = ws;
+  float* act[TRAIN_MAX_LIN + 1];
+  float* delta[TRAIN_MAX_LIN];
+  for (int l = 0; l <= nl; ++l) { act[l] = q; q += M * m.dims[l]; }
+  for (int l = 0; l < nl; ++l) { delta[l] = q; q += M * m.dims[l + 1]; }
+  float* dt = q; q += ((size_t)P * R + 3) / 4 * 4;
+  float* Y = q; q += RF;
+  float* lam = q; q += RF;
+  float* gX = q; q += RF;
+  float* lamK = q; q += 8 * RF;
+  float* gs = q; q += (size_t)R * std::max(F, m.H);
+  float *rnn_in[TRAIN_MAX_L], *rnn_hp[TRAIN_MAX_L], *rnn_out[TRAIN_MAX_L], *rnn_delta[TRAIN_MAX_L];
+  for (int l = 0; l < L; ++l) { rnn_in[l] = q; q += MB * F; rnn_hp[l] = q; q += MB * F; rnn_out[l] = q; q += MB * F; rnn_delta[l] = q; q += MB * F; }
+  float* gi = q; q += (size_t)B * F;
+  float* gh = q; q += (size_t)B * F;
+  float* dinp = q; q += (size_t)B * F;
+  float* dhp = q; q += (size_t)B * F;
+  float* hid = q; q += MB * 128;
+  float* dhid = q; q += MB * 128;
+  float* dpo = q; q += (MB * 6 + 3) / 4 * 4;
+  float* dout = q; q += MB * F;
+
+  StageCoef arow[8], brow;
+  for (int s = 0; s < S; ++s) {
+    arow[s].n = s;
+    for (int j = 0; j < 8; ++j) arow[s].c[j] = j < s ? m.a[s][j] : 0.f;
+  }
+  brow.n = S;
+  for (int j = 0; j < 8; ++j) brow.c[j] = j < S ? m.b[j] : 0.f;
+
+  // =============================== 1. tape ===============================
+  hipLaunchKernelGGL(dt_rows_kernel, EW_GRID((size_t)P * R), 0, st, ts, dt, B, P, R, m.nsub);
+  if (hc) (void)hipMemcpyAsync(Y, hc, RF * sizeof(float), hipMemcpyDeviceToDevice, st);
+  else (void)hipMemsetAsync(Y, 0, RF * sizeof(float), st);
+  for (int it = 0; it < P; ++it) {
+    if (m.with_ode) {
+      for (int j = 0; j < m.nsub; ++j) {
+        const size_t mstep = ((size_t)it * m.nsub + j) * S * R;             // first tape row of this step
+        const float* kbase = act[nl] + mstep * F;                           // K_0 of this step; K_s is S*... rows later
+        for (int s = 0; s < S; ++s) {
+          const size_t m0 = mstep + (size_t)s * R;
+          hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, act[0] + m0 * F, Y, kbase, RF, arow[s], dt + (size_t)it * R, R, F);
+          for (int l = 0; l < nl; ++l) {
+            float* o = act[l + 1] + m0 * m.dims[l + 1];
+            gemm_nt(st, act[l] + m0 * m.dims[l], m.dims[l], m.ode_w[l], m.dims[l], m.ode_b[l], o, m.dims[l + 1], R, m.dims[l + 1], m.dims[l]);
+            hipLaunchKernelGGL(act_kernel, EW_GRID((size_t)R * m.dims[l + 1]), 0, st, o, (size_t)R * m.dims[l + 1], l + 1 < nl ? m.act : 0);
+          }
+        }
+        // Y <- Y + dt * sum_s b_s K_s: the stage-input formula with the b row
+        hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, Y, Y, kbase, RF, brow, dt + (size_t)it * R, R, F);
+      }
+    }
+    for (int l = 0; l < L; ++l) {
+      float* in_l = rnn_in[l] + (size_t)it * B * F;
+      float* hp_l = rnn_hp[l] + (size_t)it * B * F;
+      float* out_l = rnn_out[l] + (size_t)it * B * F;
+      if (l == 0) hipLaunchKernelGGL(gather_interval_kernel, EW_GRID((size_t)B * F), 0, st, fused, in_l, B, P, F, it);
+      else (void)hipMemcpyAsync(in_l, rnn_out[l - 1] + (size_t)it * B * F, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(hp_l, Y + (size_t)l * B * F, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);
+      gemm_nt(st, in_l, F, m.rnn_wih[l], F, m.rnn_bih[l], gi, F, B, F, F);
+      gemm_nt(st, hp_l, F, m.rnn_whh[l], F, m.rnn_bhh[l], gh, F, B, F, F);
+      hipLaunchKernelGGL(rnn_cell_kernel, EW_GRID((size_t)B * F), 0, st, gi, gh, out_l, Y + (size_t)l * B * F, (size_t)B * F);
+    }
+  }
+  // regressor hidden layer on the top-layer outputs (interval-major rows)
+  gemm_nt(st, rnn_out[L - 1], F, m.reg_w0, F, m.reg_b0, hid, 128, (int)MB, 128, F);
+  hipLaunchKernelGGL(leaky_kernel, EW_GRID(MB * 128), 0, st, hid, MB * 128, 0.1f);
+
+  // =============================== 2. reverse sweep ===============================
+  for (int it = 0; it < P; ++it) hipLaunchKernelGGL(gather_interval_kernel, EW_GRID((size_t)B * 6), 0, st, grad_poses, dpo + (size_t)it * B * 6, B, P, 6, it);
+  hipLaunchKernelGGL(reg2_bwd_kernel, EW_GRID(MB * 128), 0, st, dpo, m.reg_w2, hid, dhid, (int)MB);
+  gemm_nt(st, dhid, 128, m.reg_w0_t, 128, nullptr, dout, F, (int)MB, F, 128);          // d out = dhid W0
+  if (grad_hT) (void)hipMemcpyAsync(lam, grad_hT, RF * sizeof(float), hipMemcpyDeviceToDevice, st);
+  else (void)hipMemsetAsync(lam, 0, RF * sizeof(float), st);
+  for (int it = P - 1; it >= 0; --it) {
+    // lam = dL/d(state after the RNN of interval it); the top layer's output also feeds the regressor
+    hipLaunchKernelGGL(add_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)(L - 1) * B * F, dout + (size_t)it * B * F, (size_t)B * F);
+    for (int l = L - 1; l >= 0; --l) {
+      float* d_l = rnn_delta[l] + (size_t)it * B * F;
+      // gradient reaching hn_l: its own state slot, plus (below the top) what the layer above sent down its input
+      hipLaunchKernelGGL(rnn_cell_bwd_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)l * B * F, l + 1 < L ? dinp : nullptr,
+                         rnn_out[l] + (size_t)it * B * F, d_l, (size_t)B * F);
+      gemm_nt(st, d_l, F, m.rnn_wih_t[l], F, nullptr, dinp, F, B, F, F);                 // d input  = delta W_ih
+      gemm_nt(st, d_l, F, m.rnn_whh_t[l], F, nullptr, dhp, F, B, F, F);                  // d hidden = delta W_hh
+      (void)hipMemcpyAsync(lam + (size_t)l * B * F, dhp, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);   // -> d evolved state
+      if (l == 0 && grad_fused) hipLaunchKernelGGL(scatter_interval_kernel, EW_GRID((size_t)B * F), 0, st, dinp, grad_fused, B, P, F, it);
+    }
+    if (m.with_ode) {
+      for (int j = m.nsub - 1; j >= 0; --j) {
+        const size_t mstep = ((size_t)it * m.nsub + j) * S * R;
+        hipLaunchKernelGGL(step_adjoint_init_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, brow, dt + (size_t)it * R, R, F);
+        for (int s = S - 1; s >= 0; --s) {
+          const size_t m0 = mstep + (size_t)s * R;
+          // K_s = tanh(.) : delta of the last Linear
+          hipLaunchKernelGGL(act_bwd_kernel, EW_GRID(RF), 0, st, lamK + (size_t)s * RF, act[nl] + m0 * F, delta[nl - 1] + m0 * F, RF, 0);
+          for (int l = nl - 1; l >= 1; --l) {
+            gemm_nt(st, delta[l] + m0 * m.dims[l + 1], m.dims[l + 1], m.ode_w_t[l], m.dims[l + 1], nullptr, gs, m.dims[l], R, m.dims[l], m.dims[l + 1]);
+            hipLaunchKernelGGL(act_bwd_kernel, EW_GRID((size_t)R * m.dims[l]), 0, st, gs, act[l] + m0 * m.dims[l], delta[l - 1] + m0 * m.dims[l],
+                               (size_t)R * m.dims[l], m.act);
+          }
+          gemm_nt(st, delta[0] + m0 * m.dims[1], m.dims[1], m.ode_w_t[0], m.dims[1], nullptr, gX, F, R, F, m.dims[1]);
+          hipLaunchKernelGGL(stage_adjoint_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, gX, arow[s], dt + (size_t)it * R, R, F);
+        }
+      }
+    }
+  }
+  if (grad_hc) (void)hipMemcpyAsync(grad_hc, lam, RF * sizeof(float), hipMemcpyDeviceToDevice, st);
+
+  // =============================== 3. weight gradients ===============================
+  if (m.with_ode) {
+    for (int l = 0; l < nl; ++l) {
+      if (g.ode_w[l]) gemm_tn(st, delta[l], m.dims[l + 1], act[l], m.dims[l], g.ode_w[l], m.dims[l], (int)M, m.dims[l + 1], m.dims[l]);
+      if (g.ode_b[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(m.dims[l + 1]), 0, st, delta[l], g.ode_b[l], (int)M, m.dims[l + 1]);
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    if (g.rnn_wih[l]) gemm_tn(st, rnn_delta[l], F, rnn_in[l], F, g.rnn_wih[l], F, (int)MB, F, F);
+    if (g.rnn_whh[l]) gemm_tn(st, rnn_delta[l], F, rnn_hp[l], F, g.rnn_whh[l], F, (int)MB, F, F);
+    if (g.rnn_bih[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(F), 0, st, rnn_delta[l], g.rnn_bih[l], (int)MB, F);
+    if (g.rnn_bhh[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(F), 0, st, rnn_delta[l], g.rnn_bhh[l], (int)MB, F);
+  }
+  if (g.reg_w0) gemm_tn(st, dhid, 128, rnn_out[L - 1], F, g.reg_w0, F, (int)MB, 128, F);
+  if (g.reg_b0) hipLaunchKernelGGL(colsum_kernel, EW_GRID(128), 0, st, dhid, g.reg_b0, (int)MB, 128);
+  if (g.reg_w2) gemm_tn(st, dpo, 6, hid, 128, g.reg_w2, 128, (int)MB, 6, 128);
+  if (g.reg_b2) hipLaunchKernelGGL(colsum_kernel, EW_GRID(6), 0, st, dpo, g.reg_b2, (int)MB, 6);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}

@@ -413,6 +413,12 @@ class DeepVIO(nn.Module):
                                              out.data_ptr(), self._stream()))
         return out
 
+    def cde_last_ms(self):
+        """Duration (ms) of the last layer of the most recent ``cde_func`` call (stage timers must be on)."""
+        ms = ctypes.c_float()
+        _lib.check(self._lib.odevio_cde_last_ms(self._plan, ctypes.cast(ctypes.pointer(ms), ctypes.c_void_p)))
+        return float(ms.value)
+
     STAGES = ("conv1", "conv2_6", "visual_head", "imu_fuse", "integrator", "regressor")
 
     def profile_enable(self, on=True, depth=1):

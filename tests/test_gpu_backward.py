@@ -1,0 +1,96 @@
+"""Gradients of the ODE-RNN pose path (odevio_ode_rnn_bwd, odevio_pose_loss) against torch.autograd through the oracle.
+
+The oracle is plain PyTorch, so autograd through ``oracle.pose_ode_rnn`` IS the reference's training-step gradient
+(scripts/train_model.py:69-78: loss = 100 * MSE(angles) + MSE(translations), backward through the solver's operations).
+It runs in float64 here so that the comparison measures the HIP path, not fp32 noise in the reference.
+Bar: 1e-3 of each gradient tensor's max."""
+import pytest
+import torch
+
+from odevio_amd import default_opt, synth, train
+from oracle import odevio_oracle as oc
+
+from test_gpu_parity import make_model
+
+pytestmark = pytest.mark.gpu
+GTOL = 1e-3
+
+
+def _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names):
+    leaves = {k: v.clone().double().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    fv64, fi64 = fv.double().requires_grad_(True), fi.double().requires_grad_(True)
+    hc64 = None if hc is None else hc.double().requires_grad_(True)
+    with_ode = opt.model_type == "ode-rnn"
+    poses, h_T = oc.pose_ode_rnn(leaves, fv64, fi64, ts, hc64, opt, dtype=torch.float64, with_ode=with_ode)
+    loss = 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3].double()) + \
+        torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:].double())
+    loss.backward()
+    out = {"fv": fv64.grad, "fi": fi64.grad, "loss": loss.detach(), "poses": poses.detach()}
+    if hc64 is not None:
+        out["hc"] = hc64.grad
+    for n in names:
+        out[n] = leaves[n].grad
+    return out
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(ode_solver="rk4"),
+    dict(ode_solver="rk4_classic", ode_substeps=2, ode_activation_fn="leaky_relu"),
+    dict(ode_solver="rk4", rnn_num_layers=3, ode_activation_fn="softplus", ode_fn_num_layers=2, ode_hidden_dim=1024),  # the reference recipe's shapes
+    dict(ode_solver="rk4", ode_activation_fn="relu", rnn_num_layers=1),
+    dict(model_type="rnn"),
+])
+@pytest.mark.parametrize("with_hc", [False, True])
+def test_ode_rnn_backward_matches_autograd_through_the_oracle(cfg, with_hc):
+    opt = default_opt(img_h=64, img_w=128, **cfg)
+    model, sd = make_model(opt, seed=71)
+    B, P, L, F = 3, 4, opt.rnn_num_layers, 768
+    g = torch.Generator().manual_seed(5)
+    fv, fi = torch.randn(B, P, 512, generator=g), torch.randn(B, P, 256, generator=g)
+    ts = synth.timestamps(B, P + 1, drop=0.3, seed=3, absolute=with_hc)
+    hc = torch.randn(L, B, F, generator=g) * 0.3 if with_hc else None
+    gts = torch.randn(B, P, 6, generator=g) * torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    names = train.pose_param_names(opt)
+    ref = _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names)
+
+    fv_d, fi_d = fv.cuda().requires_grad_(True), fi.cuda().requires_grad_(True)
+    hc_d = None if hc is None else hc.cuda().requires_grad_(True)
+    poses, h_T = train.pose_net(model, fv_d, fi_d, ts.cuda(), hc_d)
+    loss = train.pose_loss(poses, gts.cuda())
+    loss.backward()
+    model.check()
+    assert oc.rel_err(poses, ref["poses"]) < 1e-4
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-4 * abs(float(ref["loss"]))
+    errs = {"fv": oc.rel_err(fv_d.grad, ref["fv"]), "fi": oc.rel_err(fi_d.grad, ref["fi"])}
+    if hc is not None:
+        errs["hc"] = oc.rel_err(hc_d.grad, ref["hc"])
+    params = dict(model.named_parameters())
+    for n in names:
+        assert params[n].grad is not None, n
+        errs[n] = oc.rel_err(params[n].grad, ref[n])
+    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v < GTOL}
+    assert not bad, f"gradients off by more than {GTOL}: {bad}"
+
+
+def test_backward_refuses_what_is_not_built():
+    opt = default_opt(img_h=64, img_w=128, ode_solver="dopri5")
+    model, _ = make_model(opt, seed=72)
+    fv, fi = torch.randn(2, 3, 512).cuda().requires_grad_(True), torch.randn(2, 3, 256).cuda()
+    poses, _ = train.pose_net(model, fv, fi, synth.timestamps(2, 4).cuda())
+    with pytest.raises(ValueError, match="fixed-step"):
+        poses.sum().backward()
+    with pytest.raises(ValueError):
+        train.pose_net(make_model(default_opt(img_h=64, img_w=128, fuse_method="soft"), seed=1)[0], fv, fi, synth.timestamps(2, 4).cuda())
+
+
+def test_pose_loss_matches_the_reference_formula():
+    g = torch.Generator().manual_seed(1)
+    p, q = torch.randn(5, 10, 6, generator=g), torch.randn(5, 10, 6, generator=g)
+    pd = p.cuda().requires_grad_(True)
+    loss = train.pose_loss(pd, q.cuda())
+    loss.backward()
+    p64 = p.double().requires_grad_(True)
+    ref = 100 * torch.nn.functional.mse_loss(p64[:, :, :3], q[:, :, :3].double()) + torch.nn.functional.mse_loss(p64[:, :, 3:], q[:, :, 3:].double())
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
+    assert oc.rel_err(pd.grad, p64.grad) < 1e-6

@@ -542,6 +542,29 @@ def test_f16x2_range_guard_is_loud(dev):
     assert_close(poses, ref_p, what="poses after recovery")
 
 
+def test_bounds_audit_catches_a_planted_violation(dev, monkeypatch):
+    """Only with the bounds-audit build (ODEVIO_LIB=.../libodevio_audit.so): the audit must fire when an extent is
+    declared too short (ODEVIO_AUDIT_SELFTEST shaves 256 bytes off the input extent handed to the conv kernel) - and
+    redirect the access instead of faulting."""
+    from odevio_amd import _lib
+    if "audit" not in os.path.basename(_lib.LIB_PATH):
+        pytest.skip("production library: the kernels carry no bounds checks")
+    opt = default_opt(img_h=64, img_w=128)
+    model, sd = make_model(opt, seed=21)
+    img = synth.images(2, 3, 64, 128, seed=5)
+    _, inter = oc.image_encoder(sd, img, return_intermediate=True)
+    model.conv_block(1, nhwc(inter["conv1"]).cuda(), 2, 3)
+    model.check()                                                  # clean run: nothing to report
+    monkeypatch.setenv("ODEVIO_AUDIT_SELFTEST", "1")
+    model.conv_block(1, nhwc(inter["conv1"]).cuda(), 2, 3)
+    with pytest.raises(_lib.OdevioError, match="outside its buffers"):
+        model.check()
+    monkeypatch.delenv("ODEVIO_AUDIT_SELFTEST")
+    out = model.conv_block(1, nhwc(inter["conv1"]).cuda(), 2, 3)
+    model.check()
+    assert_close(out, nhwc(inter["conv2"]), what="conv2 after the self-test")
+
+
 def test_failed_forward_surfaces_without_check(dev):
     """A failed forward must not hand garbage on silently when nobody calls check(): the status words travel to pinned
     host memory behind every forward, and the next entry point reports the failure of the one before it."""

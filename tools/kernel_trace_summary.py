@@ -13,13 +13,19 @@ def main():
     rows = list(c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                           "from kernels group by name order by 3 desc"))
     tot = sum(r[2] for r in rows)
+    # WORKING dispatches: those lasting > 10 % of the kernel's longest one.  Kernels that are launched predicated (the CDE
+    # solver's stages return at once when the controller does not want them) would otherwise average in their no-ops.
+    work = {}
+    for r in rows:
+        d = [x[0] for x in c.execute("select end-start from kernels where name = ? and (end-start) > ?", (r[0], 0.1 * r[5]))]
+        work[r[0]] = (len(d), sum(d) / len(d))
     if out:
         w = csv.writer(open(out, "w"))
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "WorkingCalls", "WorkingAverageNs"])
         for r in rows:
-            w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 3), r[4], r[5]])
+            w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 3), r[4], r[5], work[r[0]][0], round(work[r[0]][1], 1)])
     for r in rows[:12]:
-        print(f"{r[0][:60]:60s} calls {r[1]:5d} avg {r[3] / 1e3:10.1f} us  {100 * r[2] / tot:6.2f} %")
+        print(f"{r[0][:60]:60s} calls {r[1]:5d} avg {r[3] / 1e3:10.1f} us  {100 * r[2] / tot:6.2f} %   working {work[r[0]][0]:5d} avg {work[r[0]][1] / 1e3:10.1f} us")
     if "--last-forward" in sys.argv:
         seq = list(c.execute("select name, grid_x, grid_y, grid_z, workgroup_x, end-start from kernels order by start"))
         idx = [i for i, r in enumerate(seq) if r[0].startswith("ingest") or r[0].startswith("conv1_kernel")]

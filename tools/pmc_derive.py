@@ -8,7 +8,10 @@ Usage: pmc_derive.py <dir with the pass directories> <kernel substring> [min dis
   ta_busy        = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8) per dispatch
   wave_wait      = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
 Each pass is a separate run of the same command, so ratios across passes assume the runs are alike (they are to ~2 %)."""
-import glob, json, sqlite3, sys
+import glob, json, os, sqlite3, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from odevio_amd._lib import source_sha  # noqa: E402
 
 root, key = sys.argv[1], sys.argv[2]
 min_ns = float(sys.argv[3]) * 1e3 if len(sys.argv) > 3 else 0
@@ -19,7 +22,7 @@ for f in sorted(glob.glob(f"{root}/**/*_results.db", recursive=True)):
          "where kernel_name like ? and (end-start) > ? group by counter_name")
     for name, n, total, dur in db.execute(q, (f"%{key}%", min_ns)):
         c[name] = {"n": n, "sum": total, "ns": dur}
-out = {"kernel": key, "counters": c}
+out = {"source_sha": source_sha(), "kernel": key, "counters": c}
 if "GRBM_GUI_ACTIVE" in c:
     g = c["GRBM_GUI_ACTIVE"]
     cyc = g["sum"] / 8.0

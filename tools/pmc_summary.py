@@ -5,7 +5,10 @@ Reads rocprofv3's rocpd sqlite output (`*_results.db`, view counters_collection)
 Corrections (MI355X_MICROARCH.md, HBM section): counters are in KB; on gfx950 FETCH_SIZE reports half of a wide
 coalesced read stream, so fetched bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact for 16-byte stores.
 """
-import collections, csv, glob, json, sqlite3, sys
+import collections, csv, glob, json, os, sqlite3, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from odevio_amd._lib import source_sha  # noqa: E402
 
 
 def rows(root, name):
@@ -22,12 +25,21 @@ def rows(root, name):
 
 
 root, n_fwd = sys.argv[1], int(sys.argv[2])
-out = {"forwards": n_fwd, "unit": "bytes per forward", "correction": "fetch = 2 x FETCH_SIZE KB x 1024 (gfx950), write = WRITE_SIZE KB x 1024", "kernels": {}}
+out = {"source_sha": source_sha(), "forwards": n_fwd, "unit": "bytes per forward (and per WORKING dispatch: dispatches lasting > 10 % of the kernel's longest one - "
+       "launches that return at once, like the predicated kernels of the CDE solver, are left out of that average)",
+       "correction": "fetch = 2 x FETCH_SIZE KB x 1024 (gfx950), write = WRITE_SIZE KB x 1024", "kernels": {}}
 for name, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-    acc = collections.defaultdict(float)
-    for kname, value, _dur in rows(root, name):
+    per = collections.defaultdict(list)
+    for kname, value, dur in rows(root, name):
         k = kname.split("(")[0].replace("void ", "")
-        acc[k] += value * 1024.0 * mult
-    for k, v in acc.items():
-        out["kernels"].setdefault(k, {})[name.lower().replace("_size", "_bytes")] = v / n_fwd
+        per[k].append((value * 1024.0 * mult, dur))
+    key = name.lower().replace("_size", "_bytes")
+    for k, lst in per.items():
+        e = out["kernels"].setdefault(k, {})
+        e[key] = sum(v for v, _ in lst) / n_fwd
+        longest = max(d for _, d in lst)
+        work = [(v, d) for v, d in lst if d > 0.1 * longest]
+        e[key + "_per_working_dispatch"] = sum(v for v, _ in work) / len(work)
+        e["working_dispatches"] = len(work)
+        e["avg_working_ns"] = round(sum(d for _, d in work) / len(work), 1)
 print(json.dumps(out, indent=1))
