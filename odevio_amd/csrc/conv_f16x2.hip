@@ -242,10 +242,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int st_cur = 0, st_nxt = T::LOOKAHEAD;   // stage holding tile j / stage to refill with tile j+LOOKAHEAD
+#ifdef ODEVIO_CONV_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
+#endif
   for (int j = 0; j < ntile; ++j) {
     if (j + T::LOOKAHEAD < ntile) next_tile();
+#ifdef ODEVIO_CONV_STAGGER
+    // experiment: the two waves of a SIMD (w, w + 4) take their DMA issue at opposite ends of the K-tile, so that one
+    // multiplies while the other feeds the DMA queue
+    if (wave >= 4) {
+      multiply(st_cur);
+      issue_tile(st_nxt);
+    } else {
+      issue_tile(st_nxt);
+      multiply(st_cur);
+    }
+#else
     issue_tile(st_nxt);                    // -> the stage tile j-1 was read from (everyone is past that barrier)
     multiply(st_cur);
+#endif
     if (T::LOOKAHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::DMAS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
