@@ -162,18 +162,23 @@ def f32_reference(opt, sd, img, imu, ts, steps=5):
 
 def cpu_baseline(opt, sd, budget_s=20.0):
     from oracle import odevio_oracle as oc  # the oracle is the CPU baseline leg, nothing else
-    nb = 1
-    img, imu, ts = synth.batch(nb, S, H, W, seed=1)
+    # the real workload once: all B sequences in one call, every host core (PyTorch's intra-op threads); then a few
+    # single-sequence calls (what round 1 reported) for the per-sequence cost
+    img, imu, ts = synth.batch(B, S, H, W, seed=1)
     with torch.no_grad():
-        oc.deepvio_forward(sd, img, imu, ts, None, opt)  # warm-up
+        oc.deepvio_forward(sd, img[:1], imu[:1], ts[:1], None, opt)  # warm-up
+        t0 = time.perf_counter()
+        oc.deepvio_forward(sd, img, imu, ts, None, opt)
+        dt_full = time.perf_counter() - t0
         t0 = time.perf_counter()
         reps = 0
         while True:
-            oc.deepvio_forward(sd, img, imu, ts, None, opt)
+            oc.deepvio_forward(sd, img[:1], imu[:1], ts[:1], None, opt)
             reps += 1
-            if time.perf_counter() - t0 > budget_s or reps >= 8:
+            if time.perf_counter() - t0 > budget_s - dt_full or reps >= 6:
                 break
         dt = (time.perf_counter() - t0) / reps
+        nb = B
         # bare RK4 step loop of the [32,768] state (the "integrator steps/s" half of the metric).  32-row GEMMs do not
         # scale to every host core (oversubscription makes them slower), so try a few thread counts and keep the best.
         F = opt.v_f_len + opt.i_f_len
@@ -195,8 +200,9 @@ def cpu_baseline(opt, sd, budget_s=20.0):
             if rate > best[0]:
                 best = (rate, nt)
         torch.set_num_threads(all_threads)
-    return {"value": nb * S / dt, "unit": "frames/s", "cores": all_threads, "kind": "port",
-            "sample": f"oracle DeepVIO.forward, {nb} sequence x {S} frames 256x512 fp32, {reps} reps, {dt:.2f} s each",
+    return {"value": nb * S / dt_full, "unit": "frames/s", "cores": all_threads, "kind": "port",
+            "sample": f"oracle DeepVIO.forward on the bench batch itself, {nb} sequences x {S} frames 256x512 fp32, one call of {dt_full:.2f} s; "
+                      f"one sequence alone: {dt:.2f} s ({S / dt:.1f} frames/s, {reps} reps)",
             "integrator_steps_per_s": best[0], "integrator_cores": best[1],
             "integrator_sample": f"{n} RK4 (3/8) steps of the [32,768] state through ODEFunc(768-512-512-512-768), best of 1/4/8/16/all threads"}
 

@@ -57,6 +57,14 @@ enum odevio_fuse { ODEVIO_FUSE_CAT = 0, ODEVIO_FUSE_SOFT = 1 };
 /* reference src/models/DeepVIO.py:45-59 */
 enum odevio_model { ODEVIO_MODEL_ODE_RNN = 0, ODEVIO_MODEL_RNN = 1, ODEVIO_MODEL_CDE = 2 };
 
+/* Arithmetic of the image encoder (everything else is plain fp32 in every mode).  Only the first two carry the 1e-4 parity
+ * claim.  The environment variable ODEVIO_CONV_MATH = f16x2 | f32 | f16 overrides the field (diagnostics). */
+enum odevio_arith {
+  ODEVIO_ARITH_FP32 = 0,      /* --dtype fp32: fp32 operands as two fp16 pieces, 3 fp16 MFMAs per product, fp32 accumulate */
+  ODEVIO_ARITH_FP32_MFMA = 1, /* --dtype fp32_mfma: the fp32-input MFMA (1/16 of the fp16 rate) */
+  ODEVIO_ARITH_FP16 = 2       /* --dtype fp16 | bf16: reduced precision, fp16 operands (one piece), fp32 accumulate */
+};
+
 /* The hot-path subset of reference scripts/config.py:29,48-51,59,62-65,68-69 + controller constants
  * of reference src/models/PoseODERNN.py:57,72 (torchode IntegralController(atol, rtol), dt0). */
 typedef struct odevio_config {
@@ -76,6 +84,8 @@ typedef struct odevio_config {
   int32_t max_steps;          /* per-interval step budget of the adaptive solvers */
   /* Neural-CDE variant, reference scripts/config.py:74-78 (used when model_type == ODEVIO_MODEL_CDE) */
   int32_t cde_hidden_dim, cde_fn_num_layers, cde_activation, cde_solver;
+  /* build extension `--dtype` (not in the reference, which is fp32-only: scripts/train_model.py:63-66): odevio_arith */
+  int32_t arith;
 } odevio_config;
 
 /* One named weight, keyed exactly like the reference state_dict, fp32 on device. */
@@ -200,6 +210,14 @@ int odevio_path_accu(const void* poses6, int32_t is_f64, const int64_t* offsets,
  * Model types ode-rnn / rnn; needs the default fp16x2 encoder. */
 int odevio_forward_u8(odevio_plan* plan, const uint8_t* img_u8, const float* imu, int32_t T, const float* ts,
                       const float* hc, int32_t B, int32_t S, float* poses, float* h_T, int32_t* stats, void* stream);
+
+/* The loader's frame resize on the device (reference src/data/KITTI_eval.py:101, src/data/utils.py:366-371:
+ * torchvision TF.resize of a PIL image = PIL.Image.resize(size, BILINEAR)): src [n,Hin,Win,3] uint8 HWC ->
+ * dst [n,Hout,Wout,3] uint8, BIT-IDENTICAL to Pillow (8-bit fixed-point triangle filter with antialiasing when shrinking,
+ * horizontal then vertical pass).  tmp = n*Hin*Wout*3 bytes of device scratch (may be NULL when only one dimension
+ * changes).  No plan needed.  The output feeds odevio_forward_u8 directly. */
+int odevio_resize_u8(const uint8_t* src, int32_t n, int32_t Hin, int32_t Win, uint8_t* dst, int32_t Hout, int32_t Wout,
+                     uint8_t* tmp, void* stream);
 
 /* Per-stage timing of odevio_forward with HIP events recorded on the caller's stream (used by bench.py for
  * the roofline figures).  Stages: 0 conv1, 1 conv2..conv6 (implicit-GEMM kernel), 2 visual head,

@@ -14,6 +14,9 @@ SOLVERS = {"dopri5": 0, "heun": 1, "tsit5": 2, "euler": 3, "rk4": 4, "runge_kutt
 RNN_TYPES = {"rnn": 0, "gru": 1}
 FUSE_METHODS = {"cat": 0, "soft": 1}
 MODEL_TYPES = {"ode-rnn": 0, "rnn": 1, "cde": 2}
+# --dtype -> odevio_arith: fp32 = fp32-grade products on the fp16 MFMA (two-piece operands), fp32_mfma = the fp32-input MFMA,
+# fp16 / bf16 = the reduced-precision encoder (its operand type on gfx950 is fp16: same MFMA rate as bf16, 3 more bits)
+DTYPES = {"fp32": 0, "fp32_mfma": 1, "fp16": 2, "bf16": 2}
 
 # every symbol include/odevio.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
@@ -21,7 +24,7 @@ SYMBOLS = [
     "odevio_check", "odevio_conv_block_fwd", "odevio_image_encoder_fwd", "odevio_imu_encoder_fwd", "odevio_fuse_fwd", "odevio_ode_func",
     "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
     "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func", "odevio_cde_last_ms",
-    "odevio_ode_rnn_bwd", "odevio_pose_loss",
+    "odevio_ode_rnn_bwd", "odevio_pose_loss", "odevio_resize_u8",
 ]
 
 
@@ -52,6 +55,7 @@ class OdevioConfig(ctypes.Structure):
         ("max_steps", ctypes.c_int32),
         ("cde_hidden_dim", ctypes.c_int32), ("cde_fn_num_layers", ctypes.c_int32),
         ("cde_activation", ctypes.c_int32), ("cde_solver", ctypes.c_int32),
+        ("arith", ctypes.c_int32),
     ]
 
 
@@ -103,6 +107,7 @@ def load():
     lib.odevio_cde_last_ms.argtypes = [vp, fp]
     lib.odevio_ode_rnn_bwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_pose_loss.argtypes = [fp, fp, i32, fp, fp, vp]
+    lib.odevio_resize_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.odevio_cde_func.argtypes = [vp, fp, fp, i32, i32, i32, fp, vp]
     lib.odevio_forward.argtypes = [vp, fp, fp, i32, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_forward_u8.argtypes = [vp, fp, fp, i32, fp, fp, i32, i32, fp, fp, vp, vp]

@@ -84,7 +84,7 @@ _FLAGS = [
     ("adjoint", _STORE_TRUE, False, "whether to use adjoint method", {}),
     # --- build extensions (not in the reference) ---
     ("ode_substeps", int, 1, "[ext] fixed sub-steps per observation interval (rk4/rk4_classic)", {}),
-    ("dtype", str, "fp32", "[ext] arithmetic type of the HIP path [fp32]", {}),
+    ("dtype", str, "fp32", "[ext] arithmetic of the image encoder [fp32 (two fp16 pieces per operand, fp32-grade), fp32_mfma, fp16, bf16 (= fp16: reduced precision)]", {}),
 ]
 # fmt: on
 

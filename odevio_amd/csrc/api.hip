@@ -18,6 +18,27 @@
 #include "integrator.h"
 #include "train.h"
 
+// roctx ranges at the two sites the reference marks with NVTX (src/models/PoseODERNN.py:103-104 "ODE", :118-119 "RNN"),
+// plus the encoders: visible in rocprofv3 --marker-trace.  libroctx64 is looked up at run time (no link dependency);
+// without it the ranges are no-ops.
+#include <dlfcn.h>
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (void* h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL)) {
+      push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+  }
+};
+struct RoctxRange {
+  static Roctx& api() { static Roctx r; return r; }
+  explicit RoctxRange(const char* name) { if (api().push) api().push(name); }
+  ~RoctxRange() { if (api().pop) api().pop(); }
+};
+
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -56,6 +77,13 @@ struct odevio_plan {
   void* conv_ws[9] = {};   // conv2..conv6 weights as two fp16 pieces (conv_f16x2.hip), [Cout][K-tile][2][32], pre-scaled
   size_t conv_ws_bytes[9] = {}, head_ws_bytes = 0;
   float* conv_scale_h[9] = {};  // BatchNorm scale with the weights' power-of-two pre-scale folded back in
+  // The same constants for the production chain, where every stored activation carries a per-layer power-of-two factor
+  // 2^act_exp (chosen at plan creation from a variance estimate, see plan_create): keeps the fp16 pieces of the
+  // activations in their normal range whatever the checkpoint's BatchNorm statistics are.  Exact: LeakyReLU is
+  // positively homogeneous and the factor is divided back out of the next layer's scale.
+  float* conv_scale_c[9] = {};
+  float* conv_shift_c[9] = {};
+  int act_exp[10] = {};
   int conv_math = 1;       // 1: fp16x2 operand split on the fp16 MFMA (default); 0: fp32-input MFMA (ODEVIO_CONV_MATH=f32)
   DevBuf pack_tmp, ingest, partial_side;
   // the inertial encoder runs beside the image encoder on its own stream (odevio_forward)
@@ -350,7 +378,13 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   } while (0)
 
   std::vector<float> w, t, sc, sh, bias;
-  if (const char* cm = getenv("ODEVIO_CONV_MATH")) {  // diagnostic override; the default is the fp32-accurate split
+  // arithmetic of the encoder: the config's `arith` (--dtype), which the diagnostic ODEVIO_CONV_MATH overrides
+  if (cfg->arith < 0 || cfg->arith > ODEVIO_ARITH_FP16) {
+    odevio_plan_destroy(p);
+    return fail(ODEVIO_ERR_BAD_ARG, "odevio_config.arith must be 0 (fp32), 1 (fp32_mfma) or 2 (fp16)");
+  }
+  p->conv_math = cfg->arith == ODEVIO_ARITH_FP32 ? 1 : (cfg->arith == ODEVIO_ARITH_FP32_MFMA ? 0 : 2);
+  if (const char* cm = getenv("ODEVIO_CONV_MATH")) {
     if (!strcmp(cm, "f32")) p->conv_math = 0;
     else if (!strcmp(cm, "f16x2")) p->conv_math = 1;
     else if (!strcmp(cm, "f16")) p->conv_math = 2;   // reduced precision: fp16 operands (h piece only), fp32 accumulate
@@ -364,6 +398,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   HIPCHK(hipMemsetAsync(p->zero_page, 0, ODEVIO_ZERO_PAGE_BYTES, st));
   p->conv_h[0] = cfg->img_h;
   p->conv_w_sp[0] = cfg->img_w;
+  double ex2_in = 1.0 / 12.0;   // second moment of the layer input in true units; frames are ToTensor() - 0.5: U(-0.5, 0.5)
   for (int i = 0; i < 9; ++i) {
     const ConvSpec& cs = kConvs[i];
     p->conv_h[i + 1] = conv_out(p->conv_h[i], cs.k, cs.stride);
@@ -424,6 +459,33 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
     }
     TRY(upload(p, &p->conv_scale[i], sc, st));
     TRY(upload(p, &p->conv_shift[i], sh, st));
+    {
+      // Activation exponent of this layer's output from a propagated second moment (inputs treated as independent,
+      // zero-mean): E[conv^2] = fan_in * mean(w^2) * E[x^2]; after BatchNorm E[y^2] = mean_c(s_c^2) E[conv^2] + mean_c(t_c^2);
+      // LeakyReLU(0.1) of a symmetric y keeps (1 + 0.01) / 2 of it.  The stored activation is out * 2^e with 2^e ~ 1 / rms(out):
+      // an fp32 value is carried as two fp16 pieces with an ABSOLUTE resolution of 2^-25, so a layer whose activations are
+      // all tiny (or huge) would lose relative accuracy (or leave the fp16 range) without it.  Networks with BatchNorm'd
+      // O(1) activations get e = 0 and bit-identical results.
+      double mw2 = 0.0, ms2 = 0.0, mt2 = 0.0;
+      for (float x : w) mw2 += (double)x * x;
+      mw2 /= (double)w.size();
+      for (int c = 0; c < cs.cout; ++c) { ms2 += (double)sc[c] * sc[c]; mt2 += (double)sh[c] * sh[c]; }
+      ms2 /= cs.cout; mt2 /= cs.cout;
+      const double econv2 = (double)cs.cin * cs.k * cs.k * mw2 * ex2_in;
+      const double eout2 = (ms2 * econv2 + mt2) * 0.505;
+      int e = 0;
+      if (eout2 > 0.0 && std::isfinite(eout2)) e = (int)std::lround(-0.5 * std::log2(eout2));
+      e = std::max(-24, std::min(24, e));
+      if (std::abs(e) <= 2) e = 0;            // already O(1): leave the constants (and the bits) alone
+      p->act_exp[i + 1] = e;
+      std::vector<float> scc(sc), shc(sh);
+      const float fs = std::ldexp(1.0f, e - p->act_exp[i]) / prescale, ft = std::ldexp(1.0f, e);
+      for (float& v : scc) v *= fs;
+      for (float& v : shc) v *= ft;
+      TRY(upload(p, &p->conv_scale_c[i], scc, st));
+      TRY(upload(p, &p->conv_shift_c[i], shc, st));
+      ex2_in = eout2;
+    }
   }
   {
     const int oh = p->conv_h[9], ow = p->conv_w_sp[9];
@@ -446,7 +508,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       TRY(dev_alloc(p, &p->head_ws, ws.size() * sizeof(uint16_t)));
       HIPCHK(hipMemcpyAsync(p->head_ws, ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
-      std::vector<float> hs((size_t)cfg->v_f_len, 1.0f / prescale);
+      std::vector<float> hs((size_t)cfg->v_f_len, std::ldexp(1.0f, -p->act_exp[9]) / prescale);   // conv6's stored output carries 2^act_exp[9]
       TRY(upload(p, &p->head_scale_h, hs, st));
     }
     TRY(wt.get("Image_net.visual_head.bias", cfg->v_f_len, bias));
@@ -676,7 +738,7 @@ static int pick_splitk_h(int M, int N, int nk) {
 // One encoder block.  Activations between blocks live in the P2 split layout when the fp16x2 kernel is in use
 // (in_split / out_split); fp32 NHWC otherwise.
 static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void* out, bool in_split, bool out_split,
-                      hipStream_t st, bool in_u8 = false) {
+                      hipStream_t st, bool in_u8 = false, bool chain = false) {
   const int P = B * (S - 1);
   const ConvSpec& cs = kConvs[i];
   if (i == 0) {
@@ -698,7 +760,8 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
       a.planes_bytes = g.planes_bytes;
       a.out_bytes = extent_of(p, out, (size_t)P * a.Ho * a.Wo * 64 * sizeof(float));
       a.wt16 = p->conv_ws[0];
-      a.scale = p->conv_scale_h[0];
+      a.scale = chain ? p->conv_scale_c[0] : p->conv_scale_h[0];
+      if (chain) a.shift = p->conv_shift_c[0];
       a.terms = p->conv_math == 2 ? 1 : 3;
       HIPCHK(launch_conv1_f16x2(a, p->n_cu, st));
     } else {
@@ -709,7 +772,9 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
   }
   if (in_split) {
     ConvSplitArgs a{};
-    a.in = in; a.w = p->conv_ws[i]; a.zeros = p->zero_page; a.scale = p->conv_scale_h[i]; a.shift = p->conv_shift[i]; a.out = out; a.status = p->status;
+    a.in = in; a.w = p->conv_ws[i]; a.zeros = p->zero_page; a.out = out; a.status = p->status;
+    a.scale = chain ? p->conv_scale_c[i] : p->conv_scale_h[i];
+    a.shift = chain ? p->conv_shift_c[i] : p->conv_shift[i];
     a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
     a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
     a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.ld_out = cs.cout; a.terms = p->conv_math == 2 ? 1 : 3;
@@ -771,17 +836,18 @@ static int ensure_act(odevio_plan* p, int P) {
 
 static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* fv, int ld_fv, hipStream_t st,
                          bool img_u8 = false) {
+  RoctxRange range("odevio: ImageEncoder");
   const int P = B * (S - 1);
   int rc;
   if ((rc = ensure_act(p, P))) return rc;
   const bool split = p->conv_math != 0;  // conv1 .. conv5_1 hand their output over in the P2 split layout
   stage_mark(p, 0, st);
-  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, false, split, st, img_u8))) return rc;
+  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, false, split, st, img_u8, split))) return rc;
   stage_mark(p, 1, st);
   float* cur = p->actA.p;
   for (int i = 1; i < 9; ++i) {
     float* nxt = (cur == p->actA.p) ? p->actB.p : p->actA.p;
-    if ((rc = conv_block(p, i, cur, B, S, nxt, split, split, st))) return rc;
+    if ((rc = conv_block(p, i, cur, B, S, nxt, split, split, st, false, split))) return rc;
     cur = nxt;
   }
   stage_mark(p, 2, st);
@@ -816,6 +882,7 @@ static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* f
 
 static int imu_encoder(odevio_plan* p, const float* imu, int B, int T, float* fi, int ld_fi, hipStream_t st,
                        DevBuf* slabs = nullptr) {
+  RoctxRange range("odevio: InertialEncoder");
   const int pps = (T - 1) / 10;
   const int P = B * pps;
   int rc;
@@ -967,6 +1034,7 @@ static int launch_integ(odevio_plan* p, IntegArgs& a, int rt, size_t lds, hipStr
 
 static int run_sequence(odevio_plan* p, const float* fused, const float* ts, const float* hc, int B, int P,
                         float* out_seq, float* hT, int32_t* stats, hipStream_t st) {
+  RoctxRange range("odevio: ODE + RNN (persistent integrator)");   // the reference's "ODE" and "RNN" ranges are one launch here
   const int L = p->cfg.rnn_num_layers;
   const int bpg_max = 8 / L;  // rows per group <= 8
   const int chunk = INTEG_GROUPS * bpg_max;
@@ -1071,6 +1139,14 @@ extern "C" int odevio_path_accu(const void* poses6, int32_t is_f64, const int64_
   ARGCHK(poses6 && offsets && mats && n_drives > 0, "odevio_path_accu: bad argument");
   HIPCHK(launch_path_accu(poses6, is_f64, offsets, n_drives, carry, mats, (hipStream_t)stream));
   return ODEVIO_OK;
+}
+
+extern "C" int odevio_resize_u8(const uint8_t* src, int32_t n, int32_t Hin, int32_t Win, uint8_t* dst, int32_t Hout, int32_t Wout,
+                                uint8_t* tmp, void* stream) {
+  ARGCHK(src && dst && n > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "odevio_resize_u8: bad argument");
+  if (Hin != Hout && Win != Wout && !tmp) return fail(ODEVIO_ERR_BAD_ARG, "odevio_resize_u8: a two-pass resize needs n*Hin*Wout*3 bytes of scratch");
+  if (resize_u8_launch(src, n, Hin, Win, dst, Hout, Wout, tmp, (hipStream_t)stream)) return fail(ODEVIO_ERR_HIP, "odevio_resize_u8: launch failed");
+  return 0;
 }
 
 extern "C" int odevio_debug_stamps(odevio_plan* p, uint64_t* out8, void* stream) {

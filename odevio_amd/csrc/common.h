@@ -147,6 +147,10 @@ void launch_pair_unpack(const void* in, float* out, size_t pixels, int C, hipStr
 hipError_t launch_path_accu(const void* poses, int is_f64, const int64_t* offsets_dev, int n_drives, const double* carry,
                             double* out, hipStream_t stream);
 
+// resize.hip: PIL-exact BILINEAR resize of uint8 HWC frames (tmp: n * Hin * Wout * 3 bytes of scratch)
+int resize_u8_launch(const unsigned char* src, int n, int Hin, int Win, unsigned char* dst, int Hout, int Wout, unsigned char* tmp,
+                     hipStream_t st);
+
 // x = h + l with fp16 pieces (h = fp16(x), l = fp16(x - h); the subtraction is exact), written to the two halves of a
 // P2 block [pixel][C/32][2][32] for 4 consecutive channels n..n+3 (n % 4 == 0).  Returns true when a value is outside
 // the fp16 range (the caller raises the plan's status word; such an activation cannot be represented).

@@ -22,6 +22,25 @@ import torch.nn as nn
 from . import _lib, weights
 
 
+def resize_frames(frames, out_h, out_w):
+    """uint8 HWC frames [..., H, W, 3] on the device -> [..., out_h, out_w, 3], bit-identical to the reference loader's
+    ``TF.resize`` of the PIL image (reference src/data/KITTI_eval.py:101; PIL BILINEAR with antialiasing)."""
+    if frames.dtype != torch.uint8 or not frames.is_cuda or frames.shape[-1] != 3:
+        raise ValueError("resize_frames takes uint8 HWC frames on the device")
+    lib = _lib.load()
+    frames = frames.contiguous()
+    lead, (h, w) = frames.shape[:-3], frames.shape[-3:-1]
+    n = 1
+    for d in lead:
+        n *= d
+    out = torch.empty(*lead, out_h, out_w, 3, device=frames.device, dtype=torch.uint8)
+    tmp = torch.empty(n * h * out_w * 3, device=frames.device, dtype=torch.uint8) if (h != out_h and w != out_w) else None
+    with torch.cuda.device(frames.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.odevio_resize_u8(frames.data_ptr(), n, h, w, out.data_ptr(), out_h, out_w, None if tmp is None else tmp.data_ptr(), stream))
+    return out
+
+
 def _conv_block(cin, cout, k, stride):
     # same child indices as the reference's conv() (Encoder.py:8-22): 0 = Conv2d(no bias), 1 = BatchNorm2d
     return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False), nn.BatchNorm2d(cout),
@@ -139,8 +158,8 @@ class DeepVIO(nn.Module):
             raise ValueError(f"model_type {opt.model_type!r} not supported")
         if opt.fuse_method not in ("cat", "soft", "hard"):
             raise ValueError(f"fuse_method {opt.fuse_method!r} not supported")
-        if getattr(opt, "dtype", "fp32") != "fp32":
-            raise ValueError("only --dtype fp32 is built (the 1e-4 parity bar applies to fp32)")
+        if getattr(opt, "dtype", "fp32") not in _lib.DTYPES:
+            raise ValueError(f"--dtype {opt.dtype!r} not supported: one of {sorted(_lib.DTYPES)} (only fp32 / fp32_mfma carry the 1e-4 parity claim)")
         self.opt = opt
         self.Image_net = _ImageNet(opt)
         self.Inertial_net = _InertialNet(opt)
@@ -191,6 +210,7 @@ class DeepVIO(nn.Module):
         c.cde_hidden_dim, c.cde_fn_num_layers = o.cde_hidden_dim, o.cde_fn_num_layers
         c.cde_activation = _lib.ACTIVATIONS.get(o.cde_activation_fn, 0)
         c.cde_solver = _lib.SOLVERS.get(o.cde_solver, 0)
+        c.arith = _lib.DTYPES[getattr(o, "dtype", "fp32")]
         return c
 
     def _ensure_plan(self):
@@ -262,8 +282,11 @@ class DeepVIO(nn.Module):
             # the normalisation is fused into the encoder's ingest pass (odevio_forward_u8)
             if not img.is_cuda:
                 raise RuntimeError("img must be a device tensor (no CPU path)")
-            if img.dim() != 5 or img.shape[-1] != 3 or tuple(img.shape[2:4]) != (self.opt.img_h, self.opt.img_w):
-                raise ValueError(f"uint8 frames must be [B,S,{self.opt.img_h},{self.opt.img_w},3], got {tuple(img.shape)}")
+            if img.dim() != 5 or img.shape[-1] != 3:
+                raise ValueError(f"uint8 frames must be [B,S,H,W,3] (HWC), got {tuple(img.shape)}")
+            if tuple(img.shape[2:4]) != (self.opt.img_h, self.opt.img_w):
+                # camera-sized frames: the loader's TF.resize (KITTI_eval.py:101) runs on the device, PIL-exact
+                img = resize_frames(img.detach(), self.opt.img_h, self.opt.img_w)
             img = img.detach().contiguous()
         else:
             img = self._dev(img, "img")

@@ -83,6 +83,31 @@ def drop_frames(poses_rel, timestamps, imus, dropout, rng):
     return out, np.asarray(timestamps)[keep_t], np.asarray(imus)[keep_imu], np.flatnonzero(keep_t)
 
 
+def training_windows(n_frames: int, seq_len: int):
+    """Sliding windows (first frame, one-past-last frame) of the TRAINING set: stride 1, ``range(0, n - seq_len)`` - the
+    reference leaves the last possible window out (src/data/KITTI_dataset.py:77)."""
+    return [(i, i + seq_len) for i in range(0, n_frames - seq_len)]
+
+
+def training_samples(poses_rel, timestamps, imus, seq_len, dropout=0.0, rng=None):
+    """The training-time sample list of one drive (reference src/data/KITTI_dataset.py:64-106): the frame-drop walk
+    (identical to the evaluator's: pose i+1 merged into pose i, timestamp / frame i and IMU rows [10i, 10i+10) removed),
+    then one sample per sliding window: -> list of dicts {"frames": kept frame indices [seq_len], "imus"
+    [10(seq_len-1)+1, 6], "gts" [seq_len-1, 6], "timestamps" [seq_len]}.  ``rng()`` returns uniforms in [0, 1)."""
+    if dropout > 0.0:
+        if rng is None:
+            raise ValueError("training_samples: dropout needs an rng (random.random after random.seed reproduces a reference run)")
+        poses_rel, timestamps, imus, kept = drop_frames(poses_rel, timestamps, imus, dropout, rng)
+    else:
+        poses_rel, timestamps, imus = np.asarray(poses_rel, dtype=np.float64), np.asarray(timestamps), np.asarray(imus)
+        kept = np.arange(len(timestamps))
+    out = []
+    for a, b in training_windows(len(timestamps), seq_len):
+        lo, hi = imu_rows(a, b)
+        out.append({"frames": np.asarray(kept[a:b]), "imus": imus[lo:hi], "gts": poses_rel[a:b - 1], "timestamps": timestamps[a:b]})
+    return out
+
+
 def _euler_to_rot(theta):
     c, s = np.cos(theta), np.sin(theta)
     one, zero = np.ones_like(c[..., 0]), np.zeros_like(c[..., 0])

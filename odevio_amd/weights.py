@@ -175,3 +175,18 @@ def filter_reference_state_dict(sd):
             continue
         out[k] = v
     return out
+
+
+def load_flownet_checkpoint(model, checkpoint):
+    """Initialise ``model.Image_net`` from a FlowNet checkpoint the way the reference does
+    (scripts/train_model.py:180-188): take ``checkpoint["state_dict"]``, keep only the keys ``Image_net`` owns (FlowNetS
+    carries decoder / flow-prediction layers the encoder does not have, and the encoder's ``visual_head`` is not in
+    FlowNet), overlay them on the current ``Image_net`` state and load that.  Returns the sorted list of keys taken.
+    Shapes are checked by ``load_state_dict`` exactly as in the reference."""
+    sd = checkpoint["state_dict"] if isinstance(checkpoint, dict) and "state_dict" in checkpoint else checkpoint
+    own = model.Image_net.state_dict()
+    take = {k: v for k, v in sd.items() if k in own}
+    own.update(take)
+    model.Image_net.load_state_dict(own)
+    model._plan_sig = None          # the device plan re-lays the weights at the next forward
+    return sorted(take)

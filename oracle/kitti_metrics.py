@@ -158,3 +158,28 @@ def drop_frames(poses_rel, timestamps, imus, dropout, rng):
         else:
             i += 1
     return np.stack(poses_rel), np.asarray(timestamps), imus, kept
+
+
+def training_samples(poses_rel, timestamps, imus, seq_len, dropout, rng):
+    """Plain-loop restatement of the training set construction for one drive (KITTI_dataset.py:64-106): the np.delete
+    drop walk, then one sample per sliding window, `range(0, len(frames) - seq_len)`.  Frames are represented by their
+    original indices (the reference pops file paths)."""
+    poses_rel = np.asarray(poses_rel, dtype=np.float64).copy()
+    timestamps = np.asarray(timestamps).copy()
+    imus = np.asarray(imus).copy()
+    frames = list(range(len(timestamps)))
+    i = 1
+    while i < len(poses_rel) - 2:
+        if dropout > 0.0 and rng() < dropout:
+            poses_rel[i] = compose_poses(poses_rel[i], poses_rel[i + 1])
+            poses_rel = np.delete(poses_rel, i + 1, axis=0)
+            timestamps = np.delete(timestamps, i, axis=0)
+            imus = np.delete(imus, np.arange(i * IMU_PER_FRAME, (i + 1) * IMU_PER_FRAME), axis=0)
+            frames.pop(i)
+        else:
+            i += 1
+    out = []
+    for i in range(0, len(frames) - seq_len):
+        out.append({"frames": frames[i:i + seq_len], "timestamps": timestamps[i:i + seq_len],
+                    "imus": imus[i * IMU_PER_FRAME:(i + seq_len - 1) * IMU_PER_FRAME + 1], "gts": poses_rel[i:i + seq_len - 1]})
+    return out

@@ -26,8 +26,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_config_struct_layout_matches_header():
-    # 19 int32 + 3 float fields, no padding: the ABI guard the library checks via struct_size
-    assert ctypes.sizeof(_lib.OdevioConfig) == 22 * 4
+    # 20 int32 + 3 float fields, no padding: the ABI guard the library checks via struct_size
+    assert ctypes.sizeof(_lib.OdevioConfig) == 23 * 4
     src = open(os.path.join(ROOT, "include", "odevio.h")).read()
     body = src[src.index("typedef struct odevio_config {"):src.index("} odevio_config;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)

@@ -475,6 +475,46 @@ def test_forward_from_uint8_frames(dev):
         model(frames[:, :, :32].cuda(), imu.cuda(), ts.cuda())
 
 
+def test_resize_matches_pillow(dev, golden_dir):
+    """the loader's TF.resize on the device, bit-identical to Pillow (integer arithmetic): the golden
+    vectors were written by Pillow itself (oracle/gen_golden_resize.py); the oracle restatement covers batched frames."""
+    import hashlib
+    from odevio_amd.deepvio import resize_frames
+    from oracle import pil_resize as pr
+    from oracle.gen_golden_resize import CASES, frame
+    g = np.load(os.path.join(golden_dir, "resize.npz"))
+    for i, (hi, wi, ho, wo, seed, kind) in enumerate(CASES):
+        got = resize_frames(torch.from_numpy(frame(hi, wi, seed, kind)).cuda(), ho, wo).cpu().numpy()
+        np.testing.assert_array_equal(got[:8], g[f"top{i}"])
+        np.testing.assert_array_equal(got[-8:], g[f"bot{i}"])
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == str(g[f"sha{i}"]), (i, kind)
+    batch = torch.randint(0, 256, (2, 3, 94, 310, 3), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    got = resize_frames(batch.cuda(), 64, 128).cpu().numpy()
+    np.testing.assert_array_equal(got, pr.resize_bilinear_u8(batch.numpy(), 64, 128))
+    with pytest.raises(ValueError):
+        resize_frames(batch.float().cuda(), 64, 128)
+
+
+def test_forward_from_camera_sized_frames(dev):
+    """Camera-sized uint8 frames go straight in: resize (PIL-exact) + normalisation + encoder all on the device; must
+    equal the forward fed with the frames the reference's loader would have produced (oracle resize, ToTensor() - 0.5)."""
+    from oracle import pil_resize as pr
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    model, sd = make_model(opt, seed=82)
+    B, S = 2, 3
+    raw = torch.randint(0, 256, (B, S, 94, 310, 3), generator=torch.Generator().manual_seed(6), dtype=torch.uint8)
+    _, imu, ts = synth.batch(B, S, 64, 128, seed=13)
+    p_raw, h_raw = model(raw.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    small = torch.from_numpy(pr.resize_bilinear_u8(raw.numpy(), 64, 128))
+    as_float = small.permute(0, 1, 4, 2, 3).float().div(255) - 0.5
+    p_f, h_f = model(as_float.cuda(), imu.cuda(), ts.cuda())
+    assert torch.equal(p_raw, p_f) and torch.equal(h_raw, h_f)
+    ref_p, ref_h = oc.deepvio_forward(sd, as_float, imu, ts, None, opt)
+    assert_close(p_raw, ref_p, what="poses from camera-sized frames")
+    assert_close(h_raw, ref_h, what="h_T from camera-sized frames")
+
+
 def test_baseline_config0_single_clip(dev):
     """BASELINE configs[0]'s shape: one clip, batch 1, seq-len 11, 256x512, RK4 fixed step, fp32."""
     opt = default_opt(ode_solver="rk4")
@@ -641,3 +681,114 @@ def test_reduced_precision_mode_reports_its_error(dev, monkeypatch, capsys):
     with capsys.disabled():
         print(f"\nODEVIO_CONV_MATH=f16: poses rel err {ep:.2e}, h_T rel err {eh:.2e} (fp32 parity bar: 1e-4)")
     assert ep < 5e-3 and eh < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# precision hardening of the fp16x2 operand split
+# ------------------------------------------------------------------------------------------------
+def _structured_frames(B, S, H, W, seed):
+    """uint8 frames with what camera frames have and noise does not: flat regions (incl. pure black / white = the ends of
+    the normalised range, -0.5 and +0.5 - 1/255...), smooth gradients, hard edges, a little sensor noise."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:H, 0:W]
+    out = np.zeros((B, S, H, W, 3), dtype=np.uint8)
+    for b in range(B):
+        for s in range(S):
+            f = np.stack([(x + 3 * s) * 255 // (W + 3 * S), (y + b) * 255 // (H + B), ((x // 8 + y // 8 + s) % 2) * 255], -1).astype(np.int32)
+            f[H // 6:H // 3, W // 5:W // 2] = 255                       # saturated
+            f[H // 2:2 * H // 3, W // 2:4 * W // 5] = 0                 # black
+            f[2 * H // 3:, :W // 4] = 128                               # flat grey: the l piece of byte/255 - 0.5 is tiny here
+            f += rng.integers(-2, 3, f.shape)
+            out[b, s] = np.clip(f, 0, 255).astype(np.uint8)
+    return torch.from_numpy(out)
+
+
+def test_structured_uint8_frames(dev, capsys):
+    """Structured frames (flat, saturated and black regions, gradients, checkerboards) through odevio_forward_u8: the parity
+    bar of the noise inputs must hold, and the encoder features must sit as close to the fp64 truth as for noise."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    model, sd = make_model(opt, seed=83)
+    B, S = 2, 4
+    frames = _structured_frames(B, S, 64, 128, seed=2)
+    _, imu, ts = synth.batch(B, S, 64, 128, seed=18)
+    as_float = frames.permute(0, 1, 4, 2, 3).float().div(255) - 0.5
+    poses, h = model(frames.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    ref_p, ref_h = oc.deepvio_forward(sd, as_float, imu, ts, None, opt)
+    assert_close(poses, ref_p, what="poses (structured frames)")
+    assert_close(h, ref_h, what="h_T (structured frames)")
+    fv = model.image_encoder(as_float.cuda())
+    truth = oc.image_encoder(sd, as_float, torch.float64)
+    e_hip, e_cpu = oc.rel_err(fv, truth), oc.rel_err(oc.image_encoder(sd, as_float), truth)
+    with capsys.disabled():
+        print(f"\nstructured frames, encoder vs fp64 truth: HIP f16x2 {e_hip:.2e}, CPU fp32 {e_cpu:.2e}")
+    assert e_hip < 5e-6
+
+
+@pytest.mark.parametrize("case", ["tiny", "huge"])
+def test_extreme_batchnorm_statistics(dev, monkeypatch, case, capsys):
+    """Checkpoints whose BatchNorm statistics push a layer's activations far from O(1): `tiny` makes conv2's outputs ~1e-4
+    (their low fp16 pieces would be subnormal: absolute resolution 2^-25) and lets conv3's BatchNorm scale them back,
+    `huge` makes conv4's outputs ~3e3 (towards the fp16 range) with conv4_1's statistics normalising them.  The plan's
+    per-layer activation exponents must keep the fp16x2 encoder as accurate as the fp32-input MFMA path."""
+    from odevio_amd import DeepVIO
+    opt = default_opt(img_h=64, img_w=128)
+    sd = weights.make_state_dict(opt, seed=84, randomize_stats=True)
+    if case == "tiny":
+        sd["Image_net.conv2.1.weight"] *= 2e-4
+        sd["Image_net.conv2.1.bias"] *= 2e-4
+        sd["Image_net.conv3.1.running_var"] *= 1e-9      # eps = 1e-5 caps the gain at 316
+        sd["Image_net.conv3.1.running_mean"] *= 2e-4
+        sd["Image_net.conv3.1.weight"] *= 30.0
+    else:
+        sd["Image_net.conv4.1.weight"] *= 3000.0
+        sd["Image_net.conv4.1.bias"] *= 3000.0
+        sd["Image_net.conv4_1.1.running_var"] *= 9e6
+        sd["Image_net.conv4_1.1.running_mean"] *= 3000.0
+    img = synth.images(2, 3, 64, 128, seed=7)
+    truth = oc.image_encoder(sd, img, torch.float64)
+    assert 0.05 < float(truth.abs().max()) < 1e3       # the modification is compensated: the features stay ordinary
+    errs = {}
+    for mode in ("f16x2", "f32"):
+        monkeypatch.setenv("ODEVIO_CONV_MATH", mode)
+        m = DeepVIO(opt, state_dict=sd).cuda()
+        fv = m.image_encoder(img.cuda())
+        m.check()
+        errs[mode] = oc.rel_err(fv, truth)
+    with capsys.disabled():
+        print(f"\nextreme BatchNorm statistics ({case}): encoder vs fp64 truth", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["f16x2"] < 1e-5 and errs["f16x2"] < 4.0 * errs["f32"] + 1e-6
+
+
+def test_elementwise_error_histogram(dev, monkeypatch, capsys):
+    """Element-wise (not tensor-max) error of conv3_1 and conv6 against an fp64 evaluation of the same block fed with the
+    same input, for the fp16x2 and the fp32-input MFMA encoders: percentiles of |err| / max|ref| and, for elements above
+    1 % of the tensor's max, of the element's own relative error."""
+    from odevio_amd import DeepVIO
+    opt = default_opt(img_h=64, img_w=128)
+    sd = weights.make_state_dict(opt, seed=85, randomize_stats=True)
+    img = synth.images(2, 3, 64, 128, seed=9)
+    _, inter = oc.image_encoder(sd, img, torch.float64, return_intermediate=True)
+    names = [n for n, _, _ in oc.IMAGE_CONVS]
+    rows = []
+    for mode in ("f16x2", "f32"):
+        monkeypatch.setenv("ODEVIO_CONV_MATH", mode)
+        m = DeepVIO(opt, state_dict=sd).cuda()
+        for layer in ("conv3_1", "conv6"):
+            i = names.index(layer)
+            x = nhwc(inter[names[i - 1]]).float()
+            ref = nhwc(inter[layer])                       # fp64, from the fp64 input (x is its fp32 rounding)
+            got = m.conv_block(i, x.cuda(), 2, 3).double().cpu()
+            err = (got - ref).abs()
+            scale = float(ref.abs().max())
+            big = ref.abs() > 0.01 * scale
+            q = lambda t, p: float(torch.quantile(t.flatten()[:1_000_000], p))
+            rows.append((mode, layer, q(err / scale, 0.5), q(err / scale, 0.999), float(err.max() / scale),
+                         q((err / ref.abs())[big], 0.5), q((err / ref.abs())[big], 0.999)))
+        m.check()
+    with capsys.disabled():
+        print("\nmode   layer     |err|/max: p50      p99.9    max      own-relative (>1% of max): p50      p99.9")
+        for r in rows:
+            print(f"{r[0]:6s} {r[1]:8s}            {r[2]:.2e} {r[3]:.2e} {r[4]:.2e}                              {r[5]:.2e} {r[6]:.2e}")
+    for r in rows:
+        assert r[4] < 1e-5 and r[6] < 1e-4, r

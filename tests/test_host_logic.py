@@ -119,3 +119,32 @@ def test_synthetic_timestamps():
     assert (d > 0.05).all() and d.max() > 0.25  # strictly ascending, multiples of the frame period with gaps
     assert ((d / 0.1).round() - d / 0.1).abs().max() < 1e-2
     assert synth.imu(2, 11).shape == (2, 101, 6) and synth.images(1, 3, 64, 128).abs().max() <= 0.5
+
+
+def test_flownet_checkpoint_loads_by_key_intersection():
+    """scripts/train_model.py:180-188: a FlowNet checkpoint ({"state_dict": ...}) carries layers the encoder does not own
+    (decoder, flow prediction) and lacks the encoder's visual_head; only the common keys are taken, the rest of Image_net
+    stays as it was."""
+    import torch
+    from odevio_amd import DeepVIO, default_opt, weights
+    opt = default_opt(img_h=64, img_w=128)
+    model = DeepVIO(opt, seed=3)
+    before = {k: v.clone() for k, v in model.Image_net.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    flownet = {k: torch.randn(v.shape, generator=g) for k, v in before.items() if k.startswith(("conv1.", "conv2.", "conv3.", "conv6."))
+               and v.is_floating_point()}
+    flownet["deconv5.0.weight"] = torch.randn(1024, 512, 4, 4, generator=g)     # FlowNetS decoder: not ours
+    flownet["predict_flow6.weight"] = torch.randn(2, 1024, 3, 3, generator=g)
+    taken = weights.load_flownet_checkpoint(model, {"state_dict": flownet, "epoch": 12})
+    after = model.Image_net.state_dict()
+    assert taken == sorted(k for k in flownet if k in before) and len(taken) > 10
+    for k in before:
+        if k in flownet:
+            assert torch.equal(after[k], flownet[k]), k
+        else:
+            assert torch.equal(after[k], before[k]), k        # conv3_1, conv4.., visual_head untouched
+    assert model._plan_sig is None
+    # a wrong shape must fail as it does in the reference (load_state_dict)
+    bad = {"state_dict": {"conv1.0.weight": torch.zeros(64, 6, 3, 3)}}
+    with pytest.raises(RuntimeError):
+        weights.load_flownet_checkpoint(model, bad)

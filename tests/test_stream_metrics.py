@@ -146,3 +146,27 @@ def test_oracle_euler_roundtrip():
         np.testing.assert_allclose(om.rot_to_euler(om.euler_to_rot(th)), th, atol=1e-12)
     a, b = rng.uniform(-0.3, 0.3, 6), rng.uniform(-0.3, 0.3, 6)
     np.testing.assert_allclose(om.pose_to_matrix(om.compose_poses(a, b)), om.pose_to_matrix(a) @ om.pose_to_matrix(b), atol=1e-12)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.4])
+def test_training_samples_match_oracle(dropout):
+    """Training-time sample construction (KITTI_dataset.py:64-106): drop walk + sliding windows, against the plain loop."""
+    n, S = 60, 11
+    poses = synth.trajectory(n, seed=8)
+    ts = np.cumsum(np.full(n, 0.1))
+    imus = np.arange((n - 1) * 10 + 1, dtype=np.float64)[:, None].repeat(6, 1)
+    random.seed(7)
+    got = stream.training_samples(poses, ts, imus, S, dropout, random.random)
+    random.seed(7)
+    ref = om.training_samples(poses, ts, imus, S, dropout, random.random)
+    assert len(got) == len(ref) and len(got) > 0
+    if dropout == 0.0:
+        assert len(got) == n - S            # the reference leaves the last window out
+    for a, b in zip(got, ref):
+        assert list(a["frames"]) == list(b["frames"])
+        np.testing.assert_array_equal(a["timestamps"], b["timestamps"])
+        np.testing.assert_array_equal(a["imus"], b["imus"])
+        np.testing.assert_allclose(a["gts"], b["gts"], rtol=0, atol=1e-12)
+        assert a["imus"].shape == ((S - 1) * 10 + 1, 6) and a["gts"].shape == (S - 1, 6) and np.all(np.diff(a["timestamps"]) > 0)
+    with pytest.raises(ValueError):
+        stream.training_samples(poses, ts, imus, S, 0.3, None)
