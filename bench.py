@@ -129,12 +129,15 @@ def pmc_traffic(kernel_key, stem="pmc_traffic"):
 
 
 def f32_reference(opt, sd, img, imu, ts, steps=5):
-    """The same forward with the encoder on the fp32-input MFMA kernels (ODEVIO_CONV_MATH=f32, read at plan creation):
+    """The same forward with the encoder on the fp32-input MFMA kernels (--dtype fp32_mfma):
     reported beside the headline so that the effect of the fp16x2 operand split is visible in one line."""
+    import copy
     from odevio_amd import DeepVIO
     old = os.environ.get("ODEVIO_CONV_MATH")
     os.environ["ODEVIO_CONV_MATH"] = "f32"
     try:
+        opt = copy.copy(opt)
+        opt.dtype = "fp32_mfma"
         m = DeepVIO(opt, seed=0)
         m.load_state_dict(sd)
         m = m.cuda()
@@ -215,7 +218,8 @@ def run_cde(args, rank, world, dist):
     from odevio_amd import DeepVIO
     Hc = args.cde_hidden
     v = Hc * 3 // 4
-    opt = default_opt(model_type="cde", cde_hidden_dim=Hc, v_f_len=v, i_f_len=Hc - v, cde_solver="dopri5")
+    opt = default_opt(model_type="cde", cde_hidden_dim=Hc, v_f_len=v, i_f_len=Hc - v, cde_solver="dopri5", dtype=args.dtype)
+    reduced = args.dtype in ("fp16", "bf16")
     model = DeepVIO(opt, seed=0)
     sd = model.state_dict() if (world == 1 and not args.no_cpu_baseline) else None
     model = model.cuda().eval()
@@ -265,12 +269,14 @@ def run_cde(args, rank, world, dist):
             model.cde_func(z, obs, 1)
             ev_ms += model.cde_last_ms() / n_ev
         model.profile_enable(False)
-        w_bytes = Hc * (Hc + 1) * Hc * 4 + Hc * (Hc + 1) * 4 + 2 * B * Hc * 4     # last-layer weights + bias + x in + f out
+        w_bytes = Hc * (Hc + 1) * Hc * (2 if reduced else 4) + Hc * (Hc + 1) * 4 + 2 * B * Hc * 4     # last-layer weights + bias + x in + f out
         gbs = w_bytes / (ev_ms * 1e-3) / 1e9
         out = {
             "metric": METRIC, "value": round(world * B * S * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if reduced else "f32", "data": "synthetic",
+            "dtype_note": ("reduced precision, OUTSIDE the 1e-4 parity claim: last layer stored as bf16 (widened exactly, fp32 multiply-accumulate), "
+                           "encoder on fp16 operands" if reduced else "fp32 weights, state, time and accumulation"),
             "config": {"workload": f"DeepVIO.forward, model_type cde: {B} sequences x {S} frames 256x512 per GPU, PoseCDE hidden {Hc} "
                                    f"(CDEFunc {Hc}-{Hc}-{Hc}-{Hc}-{Hc * (Hc + 1)}), dopri5 rtol 1e-4 atol 1e-6, eval mode, window "
                                    f"t = {args.cde_t0:.2f} .. {args.cde_t0 + 1.0:.2f} s (piece 1 of the rectilinear control path: every feature "
@@ -332,6 +338,8 @@ def main():
     ap.add_argument("--cde-t0", type=float, default=1.0,
                     help="first timestamp of the synthetic window (eval mode = raw time): 1.0 puts the window on piece 1 of the control "
                          "path, where dX/dt moves every feature channel and each evaluation streams the whole last layer")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp32_mfma", "fp16", "bf16"],
+                    help="arithmetic of the HIP path (build extension; only fp32 / fp32_mfma carry the 1e-4 parity claim)")
     ap.add_argument("--ode-solver", default="rk4")
     ap.add_argument("--drop", type=float, default=0.0, help="frame-drop probability of the synthetic timestamps")
     args = ap.parse_args()
@@ -363,8 +371,12 @@ def main():
     if args.model == "cde":
         return run_cde(args, rank, world, dist)
 
+    global CONV_MATH, MFMA_PER_PRODUCT
+    if "ODEVIO_CONV_MATH" not in os.environ:      # --dtype picks the arithmetic; the environment variable (diagnostic) overrides it
+        CONV_MATH = {"fp32": "f16x2", "fp32_mfma": "f32", "fp16": "f16", "bf16": "f16"}[args.dtype]
+        MFMA_PER_PRODUCT = {"f16x2": 3, "f32": 1, "f16": 1}[CONV_MATH]
     from odevio_amd import DeepVIO
-    opt = default_opt(ode_solver=args.ode_solver)
+    opt = default_opt(ode_solver=args.ode_solver, dtype=args.dtype)
     model = DeepVIO(opt, seed=0)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.cuda()

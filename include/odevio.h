@@ -219,6 +219,12 @@ int odevio_forward_u8(odevio_plan* plan, const uint8_t* img_u8, const float* imu
 int odevio_resize_u8(const uint8_t* src, int32_t n, int32_t Hin, int32_t Win, uint8_t* dst, int32_t Hout, int32_t Wout,
                      uint8_t* tmp, void* stream);
 
+/* Host-only (no GPU needed): the fixed-point coefficient table odevio_resize_u8 uses for one axis - Pillow's
+ * precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter.  bounds [out_size][2] = (first input index, count),
+ * kk [out_size][*ksize]; kk_capacity = ints available in kk (>= out_size * (2 * ceil(max(in/out, 1)) + 1)).
+ * Test hook: compared with the oracle on the CPU and run under AddressSanitizer (make ASAN=1). */
+int odevio_resize_table(int32_t in_size, int32_t out_size, int32_t* ksize, int32_t* bounds, int32_t* kk, int32_t kk_capacity);
+
 /* Per-stage timing of odevio_forward with HIP events recorded on the caller's stream (used by bench.py for
  * the roofline figures).  Stages: 0 conv1, 1 conv2..conv6 (implicit-GEMM kernel), 2 visual head,
  * 3 inertial encoder + fusion, 4 persistent ODE-RNN integrator, 5 pose regressor. */

@@ -599,6 +599,22 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       TRY(upload(p, &db, bias, st));
       p->cde.w[l] = dw;
       p->cde.b[l] = db;
+      if (l == nh && p->conv_math == 2) {
+        // reduced-precision mode (--dtype bf16 / fp16): the last layer - 99.9 % of the model's bytes - is ALSO kept as bf16
+        // (round to nearest even); the weight-stream kernel then moves half the bytes and widens in registers
+        std::vector<uint16_t> h16(w.size());
+        for (size_t i = 0; i < w.size(); ++i) {
+          uint32_t u;
+          memcpy(&u, &w[i], 4);
+          if ((u & 0x7fffffffu) > 0x7f800000u) h16[i] = (uint16_t)((u >> 16) | 0x40);   // NaN stays a NaN
+          else h16[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        void* d16 = nullptr;
+        TRY(dev_alloc(p, &d16, h16.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpyAsync(d16, h16.data(), h16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        p->cde.w_last16 = d16;
+      }
     }
   }
   // ---- RNN stack: virtual columns over K = [input | hidden]
@@ -1147,6 +1163,11 @@ extern "C" int odevio_resize_u8(const uint8_t* src, int32_t n, int32_t Hin, int3
   if (Hin != Hout && Win != Wout && !tmp) return fail(ODEVIO_ERR_BAD_ARG, "odevio_resize_u8: a two-pass resize needs n*Hin*Wout*3 bytes of scratch");
   if (resize_u8_launch(src, n, Hin, Win, dst, Hout, Wout, tmp, (hipStream_t)stream)) return fail(ODEVIO_ERR_HIP, "odevio_resize_u8: launch failed");
   return 0;
+}
+
+extern "C" int odevio_resize_table(int32_t in_size, int32_t out_size, int32_t* ksize, int32_t* bounds, int32_t* kk, int32_t kk_capacity) {
+  const int rc = resize_table_host(in_size, out_size, ksize, bounds, kk, kk_capacity);
+  return rc ? fail(rc, "odevio_resize_table: bad argument (sizes > 0, kk_capacity >= out_size * ksize)") : 0;
 }
 
 extern "C" int odevio_debug_stamps(odevio_plan* p, uint64_t* out8, void* stream) {

@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void cde_hidden_kernel(CdeWhen wh, const float
 // Ring: 8 slots per wave, piece p + 7 is requested before piece p is multiplied; `s_waitcnt vmcnt(28)` = all but the 7
 // youngest pieces have landed.  Past the last block the stream re-requests its last piece (unused) so that the counts
 // stay exact; nothing is ever requested outside the weight matrix.
-// TW = float (fp32 weights, the parity path) or __bf16-as-uint16 (reduced-precision storage: half the stream; converted
-// exactly to fp32 before the same fp32 MFMA, outside the 1e-4 claim).
+// BF16 = false: fp32 weights, the parity path.  BF16 = true (--dtype bf16 / fp16): the last layer stored as bf16 (half the
+// stream), widened exactly to fp32 in registers and multiplied on the same fp32 MFMA with fp32 x and fp32 accumulation;
+// outside the 1e-4 claim (the weights carry 8 significant bits).
 // ---------------------------------------------------------------------------------------------------------------------
 #define CS_SLOTS 8
 #define CS_AHEAD 7
@@ -151,12 +152,15 @@ __global__ __launch_bounds__(256) void cde_hidden_kernel(CdeWhen wh, const float
 #define CS_WAVE_LDS (CS_SLOTS * CS_PIECE)
 #define CS_LDS (4 * CS_WAVE_LDS + 4096)   // rings + per-wave partial sums [8 h-groups][4 waves][16]... see red
 
-template <int H>
+template <int H, bool BF16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void cde_stream_kernel(
-    CdeWhen wh, const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+    CdeWhen wh, const float* __restrict__ x, const void* __restrict__ Wv, const float* __restrict__ bias,
     const float* __restrict__ obs, float* __restrict__ out, int B, int L, int C) {
-  constexpr int NP = H / 64;      // pieces per 16-row block
-  constexpr int NS = H / 16;      // MFMA k-steps per block (4 MFMAs each)
+  constexpr int WB = BF16 ? 2 : 4;          // bytes per stored weight
+  constexpr int PK = 256 / WB;              // k-columns per piece (a piece is 16 rows x 256 bytes): 64 (fp32) or 128 (bf16)
+  constexpr int NP = H / PK;                // pieces per 16-row block
+  constexpr int NS = H / 16;                // float4 x fragments per lane over the whole K range
+  const unsigned char* W = reinterpret_cast<const unsigned char*>(Wv);
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   if (!cde_wanted(wh)) return;
   const int seg = cde_seg(wh);
@@ -193,8 +197,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             *reinterpret_cast<const f32x4*>(x + (size_t)(b0 + min(row, nb - 1)) * H + 4 * c4);
       }
       __syncthreads();
+      // fp32 storage: fragment s covers k = 16 s + 4 q .. +3 (one 16-byte chunk of the row = 4 weights);
+      // bf16 storage: a 16-byte chunk holds 8 weights, k = 32 (s / 2) + 8 q + 4 (s % 2) .. +3
 #pragma unroll
-      for (int s = 0; s < NS; ++s) xv[s] = *reinterpret_cast<const f32x4*>(xs + r * XLD + 16 * s + 4 * q);
+      for (int s = 0; s < NS; ++s) {
+        const int k = BF16 ? 32 * (s >> 1) + 8 * q + 4 * (s & 1) : 16 * s + 4 * q;
+        xv[s] = *reinterpret_cast<const f32x4*>(xs + r * XLD + k);
+      }
       __syncthreads();   // everyone has its fragments: the ring may be filled
     }
     // ---- the two cursors over this wave's (h, block) items: `c*` is multiplied, `d*` is requested (7 pieces ahead)
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int d = 0; d < 4; ++d) {
         const int row = 4 * d + d_row;
         const int c = min(dblk * 16 + row, C - 1);   // rows past C re-read the last row (masked in the epilogue)
-        d_ptr[d] = reinterpret_cast<const unsigned char*>(W + ((size_t)dh * C + c) * H) + ((d_slot ^ row) & 15) * 16;
+        d_ptr[d] = W + ((size_t)dh * C + c) * H * WB + ((d_slot ^ row) & 15) * 16;
       }
     };
     auto d_issue = [&](int slot) __attribute__((always_inline)) {
@@ -256,13 +265,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int st = 0; st < 4; ++st) {
-            const f32x4 xs = xv[4 * pc + st];
-            if (st & 1) {
+            if (BF16) {
+              // 8 bf16 weights per lane and read: widened exactly to fp32 (a bf16 is the upper half of an fp32), two groups of 4
+              const unsigned* u = reinterpret_cast<const unsigned*>(&wv[st]);
+              const f32x4 xa = xv[8 * pc + 2 * st], xb = xv[8 * pc + 2 * st + 1];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[st][j], xs[j], acc1, 0, 0, 0);
+              for (int j = 0; j < 4; ++j) {
+                const float w = __uint_as_float(j & 1 ? (u[j >> 1] & 0xffff0000u) : (u[j >> 1] << 16));
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xa[j], acc0, 0, 0, 0);
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float w = __uint_as_float(j & 1 ? (u[2 + (j >> 1)] & 0xffff0000u) : (u[2 + (j >> 1)] << 16));
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xb[j], acc1, 0, 0, 0);
+              }
             } else {
+              const f32x4 xs = xv[4 * pc + st];
+              if (st & 1) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[st][j], xs[j], acc0, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[st][j], xs[j], acc1, 0, 0, 0);
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[st][j], xs[j], acc0, 0, 0, 0);
+              }
             }
           }
         }
@@ -620,16 +645,22 @@ void cde_launch_hidden(const CdeWhen& wh, const float* x, const float* W, const 
     hipLaunchKernelGGL(cde_linear_kernel, dim3((H + 3) / 4), dim3(256), 0, st, wh, x, W, bias, out, B, H, H, H, act);
 }
 
-template <int H>
-static hipError_t launch_stream(const CdeModel& m, const CdeWhen& wh, const float* x, const float* obs, int B, int L, float* out, hipStream_t st) {
+template <int H, bool BF16>
+static hipError_t launch_stream_t(const CdeModel& m, const CdeWhen& wh, const float* x, const float* obs, int B, int L, float* out, hipStream_t st) {
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(attr_mask)) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cde_stream_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cde_stream_kernel<H, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
     if (e != hipSuccess) return e;
   }
   const int grid = std::min(m.n_cu > 0 ? m.n_cu : 256, H);
-  hipLaunchKernelGGL(cde_stream_kernel<H>, dim3(grid), dim3(256), CS_LDS, st, wh, x, m.w[m.n_hidden], m.b[m.n_hidden], obs, out, B, L, m.C);
+  const void* W = BF16 ? m.w_last16 : (const void*)m.w[m.n_hidden];
+  hipLaunchKernelGGL((cde_stream_kernel<H, BF16>), dim3(grid), dim3(256), CS_LDS, st, wh, x, W, m.b[m.n_hidden], obs, out, B, L, m.C);
   return hipSuccess;
+}
+// fp32 weights (the parity path), or the bf16 copy of the last layer when the plan carries one (reduced-precision mode)
+template <int H>
+static hipError_t launch_stream(const CdeModel& m, const CdeWhen& wh, const float* x, const float* obs, int B, int L, float* out, hipStream_t st) {
+  return m.w_last16 ? launch_stream_t<H, true>(m, wh, x, obs, B, L, out, st) : launch_stream_t<H, false>(m, wh, x, obs, B, L, out, st);
 }
 
 int cde_launch_last(const CdeModel& m, const CdeWhen& wh, const float* x, const float* obs, int B, int L, float* out, hipStream_t st) {

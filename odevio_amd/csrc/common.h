@@ -151,6 +151,8 @@ hipError_t launch_path_accu(const void* poses, int is_f64, const int64_t* offset
 int resize_u8_launch(const unsigned char* src, int n, int Hin, int Win, unsigned char* dst, int Hout, int Wout, unsigned char* tmp,
                      hipStream_t st);
 
+int resize_table_host(int in_size, int out_size, int* ksize, int* bounds, int* kk, int kk_capacity);
+
 // x = h + l with fp16 pieces (h = fp16(x), l = fp16(x - h); the subtraction is exact), written to the two halves of a
 // P2 block [pixel][C/32][2][32] for 4 consecutive channels n..n+3 (n % 4 == 0).  Returns true when a value is outside
 // the fp16 range (the caller raises the plan's status word; such an activation cannot be represented).

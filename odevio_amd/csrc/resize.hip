@@ -11,6 +11,7 @@
 // oracle/pil_resize.py restates the same algorithm in numpy and is pinned against Pillow itself (tests/golden/resize.npz).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -62,6 +63,18 @@ static void build_table(int in_size, int out_size, ResizeTable& t) {
     t.bounds[2 * xx] = xmin;
     t.bounds[2 * xx + 1] = xmax;
   }
+}
+
+// Host-only view of the table (tests: compared with the oracle's on the CPU; exercised by the ASan driver)
+int resize_table_host(int in_size, int out_size, int* ksize, int* bounds, int* kk, int kk_capacity) {
+  if (in_size <= 0 || out_size <= 0 || !ksize || !bounds || !kk) return ODEVIO_ERR_BAD_ARG;
+  ResizeTable t;
+  build_table(in_size, out_size, t);
+  *ksize = t.ksize;
+  if ((size_t)kk_capacity < t.kk.size()) return ODEVIO_ERR_BAD_ARG;
+  std::copy(t.bounds.begin(), t.bounds.end(), bounds);
+  std::copy(t.kk.begin(), t.kk.end(), kk);
+  return 0;
 }
 
 __device__ __forceinline__ unsigned char clip8(int v) {

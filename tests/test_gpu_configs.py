@@ -101,3 +101,32 @@ def test_cde_dopri5_step_counts_hidden_512(dev):
     assert (n_steps, n_acc) == (tr["n_steps"], tr["n_accepted"])
     assert_close(z0, ref_z0, what="z0")
     assert_close(poses, ref_p, what="poses")
+
+
+def test_cde_bf16_weight_stream_reports_its_error(dev, capsys):
+    """--dtype bf16 on the Neural-CDE path (the flavour BASELINE configs[4] names; the reference is fp32-only): the last
+    layer is stored as bf16 (half the weight stream), widened exactly and multiplied in fp32.  OUTSIDE the 1e-4 parity
+    claim: it reports its error against the fp32 oracle and must stay within what 8-bit significands allow; with weights
+    that ARE bf16 numbers it must agree with the fp32 path to fp32 rounding."""
+    opt = default_opt(img_h=64, img_w=128, model_type="cde", cde_hidden_dim=512, v_f_len=384, i_f_len=128, cde_solver="rk4", dtype="bf16")
+    sd = weights.make_state_dict(opt, seed=66, randomize_stats=True)
+    model, _ = make_model(opt, seed=66)
+    B, P = 3, 3
+    g = torch.Generator().manual_seed(13)
+    fv, fi = torch.randn(B, P, 384, generator=g) * 0.5, torch.randn(B, P, 128, generator=g) * 0.5
+    ts = synth.timestamps(B, P + 1, seed=8) + 1.05
+    poses, z0 = model.pose_cde(fv.cuda(), fi.cuda(), ts.cuda(), None)
+    model.check()
+    ref_p, ref_z0, _ = oc.pose_cde(sd, fv, fi, ts, None, None, opt, training=False)
+    e = oc.rel_err(poses, ref_p)
+    with capsys.disabled():
+        print(f"\n--dtype bf16, PoseCDE hidden 512: poses rel err {e:.2e} vs the fp32 oracle (fp32 parity bar: 1e-4)")
+    assert e < 3e-2
+    # weights rounded to bf16 beforehand: the bf16 stream is then exact, and the fp32 bar applies again
+    key = "Pose_net.cde_func.net.6.weight"
+    sd_r = dict(sd)
+    sd_r[key] = sd[key].to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd_r)
+    poses_r, _ = model.pose_cde(fv.cuda(), fi.cuda(), ts.cuda(), None)
+    ref_r, _, _ = oc.pose_cde(sd_r, fv, fi, ts, None, None, opt, training=False)
+    assert_close(poses_r, ref_r, what="poses with bf16-representable last-layer weights")

@@ -472,7 +472,7 @@ def test_forward_from_uint8_frames(dev):
     assert_close(p_u8, ref_p, what="poses from uint8 frames")
     assert_close(h_u8, ref_h, what="h_T from uint8 frames")
     with pytest.raises(ValueError):
-        model(frames[:, :, :32].cuda(), imu.cuda(), ts.cuda())
+        model(frames.permute(0, 1, 4, 2, 3).contiguous().cuda(), imu.cuda(), ts.cuda())   # CHW uint8: the entry takes HWC frames
 
 
 def test_resize_matches_pillow(dev, golden_dir):
@@ -564,14 +564,25 @@ def test_f32_mfma_encoder_mode(dev, monkeypatch):
 
 def test_f16x2_range_guard_is_loud(dev):
     """An encoder activation beyond the fp16 range cannot be carried as two fp16 pieces: the epilogue raises the
-    status word and check() fails instead of returning inf/nan poses silently."""
+    status word and check() fails instead of returning inf/nan poses silently.  The plan's per-layer activation exponents
+    (a power of two per layer, from a variance estimate at plan creation) absorb up to 2^24 of mis-scaling first: a
+    checkpoint whose conv1 outputs are ~1e5 - beyond fp16 as they stand - still runs, and accurately."""
     from odevio_amd._lib import OdevioError
     opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
     model, sd = make_model(opt, seed=93)
-    big = {k: v.clone() for k, v in sd.items()}
-    big["Image_net.conv1.0.weight"] *= 3e6          # conv1 outputs ~1e5
-    model.load_state_dict(big)
     img, imu, ts = synth.batch(1, 3, 64, 128, seed=15)
+    big = {k: v.clone() for k, v in sd.items()}
+    big["Image_net.conv1.0.weight"] *= 3e6          # conv1 outputs ~1e5, brought back by conv2's BatchNorm statistics
+    big["Image_net.conv2.1.running_var"] *= 9e12
+    big["Image_net.conv2.1.running_mean"] *= 3e6
+    model.load_state_dict(big)
+    poses, _ = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    ref_p, _ = oc.deepvio_forward(big, img, imu, ts, None, opt)
+    assert_close(poses, ref_p, what="poses with conv1 activations ~1e5 (absorbed by the activation exponent)")
+    huge = {k: v.clone() for k, v in sd.items()}
+    huge["Image_net.conv1.0.weight"] *= 1e20        # beyond what a 2^24 exponent can absorb
+    model.load_state_dict(huge)
     model(img.cuda(), imu.cuda(), ts.cuda())
     with pytest.raises(OdevioError, match="fp16x2 range"):
         model.check()
@@ -612,7 +623,7 @@ def test_failed_forward_surfaces_without_check(dev):
     opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
     model, sd = make_model(opt, seed=93)
     big = {k: v.clone() for k, v in sd.items()}
-    big["Image_net.conv1.0.weight"] *= 3e6
+    big["Image_net.conv1.0.weight"] *= 1e20
     model.load_state_dict(big)
     img, imu, ts = synth.batch(1, 3, 64, 128, seed=15)
     model(img.cuda(), imu.cuda(), ts.cuda())          # raises the range word on the device; returns normally
@@ -792,3 +803,20 @@ def test_elementwise_error_histogram(dev, monkeypatch, capsys):
             print(f"{r[0]:6s} {r[1]:8s}            {r[2]:.2e} {r[3]:.2e} {r[4]:.2e}                              {r[5]:.2e} {r[6]:.2e}")
     for r in rows:
         assert r[4] < 1e-5 and r[6] < 1e-4, r
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("fp32_mfma", 1e-4), ("fp16", 5e-3), ("bf16", 5e-3)])
+def test_dtype_flag_selects_the_arithmetic(dev, dtype, tol):
+    """--dtype (build extension; the reference is fp32-only) picks the encoder's arithmetic through the config, not an
+    environment variable: fp32 (two fp16 pieces per operand) and fp32_mfma hold the 1e-4 bar, fp16 / bf16 are the reduced mode."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", dtype=dtype)
+    model, sd = make_model(opt, seed=86)
+    img, imu, ts = synth.batch(2, 4, 64, 128, seed=19)
+    poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    ref_p, ref_h = oc.deepvio_forward(sd, img, imu, ts, None, opt)
+    assert oc.rel_err(poses, ref_p) < tol and oc.rel_err(h, ref_h) < tol
+    if dtype == "bf16":
+        from odevio_amd import DeepVIO
+        with pytest.raises(ValueError):
+            DeepVIO(default_opt(img_h=64, img_w=128, dtype="fp8"))

@@ -37,3 +37,21 @@ def test_batched_frames_resize_like_single_ones():
     out = pr.resize_bilinear_u8(batch, 16, 32)
     assert out.shape == (2, 3, 16, 32, 3)
     np.testing.assert_array_equal(out[1, 2], pr.resize_bilinear_u8(batch[1, 2], 16, 32))
+
+
+@pytest.mark.parametrize("sizes", [(1241, 512), (376, 256), (1226, 512), (64, 96), (7, 7), (1, 3)])
+def test_library_host_table_equals_oracle(sizes):
+    """The library's host-side coefficient table (what odevio_resize_u8 uploads) against the oracle's, entry by entry."""
+    import ctypes
+    from odevio_amd import _lib
+    lib = _lib.load()
+    n_in, n_out = sizes
+    bounds, kk = pr.coeffs(n_in, n_out)
+    ks = ctypes.c_int32()
+    b = (ctypes.c_int32 * (2 * n_out))()
+    k = (ctypes.c_int32 * (n_out * kk.shape[1]))()
+    rc = lib.odevio_resize_table(n_in, n_out, ctypes.cast(ctypes.pointer(ks), ctypes.c_void_p), ctypes.cast(b, ctypes.c_void_p),
+                                 ctypes.cast(k, ctypes.c_void_p), n_out * kk.shape[1])
+    assert rc == 0 and ks.value == kk.shape[1]
+    np.testing.assert_array_equal(np.asarray(b[:]).reshape(n_out, 2), bounds)
+    np.testing.assert_array_equal(np.asarray(k[:]).reshape(n_out, -1), kk)
