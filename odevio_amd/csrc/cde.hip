@@ -30,6 +30,7 @@
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float cde_act(float v, int act) {
   switch (act) {
@@ -143,8 +144,9 @@ __global__ __launch_bounds__(256) void cde_hidden_kernel(CdeWhen wh, const float
 // youngest pieces have landed.  Past the last block the stream re-requests its last piece (unused) so that the counts
 // stay exact; nothing is ever requested outside the weight matrix.
 // BF16 = false: fp32 weights, the parity path.  BF16 = true (--dtype bf16 / fp16): the last layer stored as bf16 (half the
-// stream), widened exactly to fp32 in registers and multiplied on the same fp32 MFMA with fp32 x and fp32 accumulation;
-// outside the 1e-4 claim (the weights carry 8 significant bits).
+// stream) and multiplied on the bf16 MFMA (v_mfma_f32_16x16x32_bf16: x rounded to bf16 once per launch, fp32
+// accumulation; 1/8 of the MFMA instructions, so the kernel stays a pure stream); bias, tanh, the contraction with
+// dX/dt, the state and the controller stay fp32.  Outside the 1e-4 claim (8 significant bits per operand).
 // ---------------------------------------------------------------------------------------------------------------------
 #define CS_SLOTS 8
 #define CS_AHEAD 7
@@ -186,7 +188,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- x fragments of the whole K range, in registers: xv[s] = x[b0 + r][16 s + 4 q .. +3].  Staged through LDS (the
     // ring is idle here): one coalesced round trip to L2 for the workgroup instead of NS dependent ones per lane.  Rows
     // past nb re-read row nb - 1: their MFMA columns are computed and never stored.
-    f32x4 xv[NS];
+    f32x4 xv[BF16 ? 1 : NS];
+    bf16x8 xh[BF16 ? NS / 2 : 1];
     {
       constexpr int XLD = H + 4;   // row stride in floats: the +4 spreads the 16 rows of a fragment read over the bank quads
       float* xs = reinterpret_cast<float*>(lds);
@@ -197,12 +200,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             *reinterpret_cast<const f32x4*>(x + (size_t)(b0 + min(row, nb - 1)) * H + 4 * c4);
       }
       __syncthreads();
-      // fp32 storage: fragment s covers k = 16 s + 4 q .. +3 (one 16-byte chunk of the row = 4 weights);
-      // bf16 storage: a 16-byte chunk holds 8 weights, k = 32 (s / 2) + 8 q + 4 (s % 2) .. +3
+      // fp32 storage: fragment s covers k = 16 s + 4 q .. +3 (one 16-byte chunk of the row = 4 weights).
+      // bf16 storage: a 16-byte chunk holds 8 weights = the 8 k-values one lane feeds to v_mfma_f32_16x16x32_bf16
+      // (k = 32 s + 8 q .. +7); x is rounded to bf16 once here (RNE) and kept as 8-element fragments xh[s].
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const int k = BF16 ? 32 * (s >> 1) + 8 * q + 4 * (s & 1) : 16 * s + 4 * q;
-        xv[s] = *reinterpret_cast<const f32x4*>(xs + r * XLD + k);
+        if (BF16) {
+          if (s < NS / 2) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xs + r * XLD + 32 * s + 8 * q);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xs + r * XLD + 32 * s + 8 * q + 4);
+            bf16x8 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = (__bf16)a[j]; h[4 + j] = (__bf16)b[j]; }
+            xh[s] = h;
+          }
+        } else {
+          xv[s] = *reinterpret_cast<const f32x4*>(xs + r * XLD + 16 * s + 4 * q);
+        }
       }
       __syncthreads();   // everyone has its fragments: the ring may be filled
     }
@@ -266,19 +280,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int st = 0; st < 4; ++st) {
             if (BF16) {
-              // 8 bf16 weights per lane and read: widened exactly to fp32 (a bf16 is the upper half of an fp32), two groups of 4
-              const unsigned* u = reinterpret_cast<const unsigned*>(&wv[st]);
-              const f32x4 xa = xv[8 * pc + 2 * st], xb = xv[8 * pc + 2 * st + 1];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float w = __uint_as_float(j & 1 ? (u[j >> 1] & 0xffff0000u) : (u[j >> 1] << 16));
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xa[j], acc0, 0, 0, 0);
-              }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float w = __uint_as_float(j & 1 ? (u[2 + (j >> 1)] & 0xffff0000u) : (u[2 + (j >> 1)] << 16));
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xb[j], acc1, 0, 0, 0);
-              }
+              // 8 bf16 weights per lane and read = one operand of the bf16 MFMA (K = 32 per instruction), fp32 accumulate
+              const bf16x8 wh = __builtin_bit_cast(bf16x8, wv[st]);
+              if (st & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[4 * pc + st], acc1, 0, 0, 0);
+              else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[4 * pc + st], acc0, 0, 0, 0);
             } else {
               const f32x4 xs = xv[4 * pc + st];
               if (st & 1) {

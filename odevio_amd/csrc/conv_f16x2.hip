@@ -242,31 +242,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int st_cur = 0, st_nxt = T::LOOKAHEAD;   // stage holding tile j / stage to refill with tile j+LOOKAHEAD
-#ifdef ODEVIO_CONV_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
-#endif
+#if defined(ODEVIO_EXP_NODMA)
+  // timing experiment (results are wrong): the K loop without staging - fragment reads + MFMAs on whatever the prologue staged
+  for (int j = 0; j < ntile; ++j) multiply(T::LOOKAHEAD == 2 ? (j & 1) : 0);   // only stages the prologue filled
+#elif defined(ODEVIO_EXP_NOMFMA)
+  // timing experiment (results are wrong): staging, waits and barriers only
   for (int j = 0; j < ntile; ++j) {
     if (j + T::LOOKAHEAD < ntile) next_tile();
-#ifdef ODEVIO_CONV_STAGGER
-    // experiment: the two waves of a SIMD (w, w + 4) take their DMA issue at opposite ends of the K-tile, so that one
-    // multiplies while the other feeds the DMA queue
-    if (wave >= 4) {
-      multiply(st_cur);
-      issue_tile(st_nxt);
-    } else {
-      issue_tile(st_nxt);
-      multiply(st_cur);
-    }
-#else
-    issue_tile(st_nxt);                    // -> the stage tile j-1 was read from (everyone is past that barrier)
-    multiply(st_cur);
-#endif
+    issue_tile(st_nxt);
     if (T::LOOKAHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::DMAS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     st_nxt = st_cur;
     st_cur = st_cur + 1 == T::NSTAGE ? 0 : st_cur + 1;
   }
+  multiply(0);
+#else
+  for (int j = 0; j < ntile; ++j) {
+    if (j + T::LOOKAHEAD < ntile) next_tile();
+    issue_tile(st_nxt);                    // -> the stage tile j-1 was read from (everyone is past that barrier)
+    multiply(st_cur);
+    if (T::LOOKAHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::DMAS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    st_nxt = st_cur;
+    st_cur = st_cur + 1 == T::NSTAGE ? 0 : st_cur + 1;
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS
 
   // ---- epilogue.  C/D map of the 16x16 MFMA: column (= pixel) = lane&15, row (= channel) = 4*(lane>>4) + r
