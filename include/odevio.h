@@ -165,8 +165,10 @@ int odevio_cde_fwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, co
  * `grads`: name = the reference state_dict key (Pose_net.ode_func.net.{0,2,..}.{weight,bias},
  * Pose_net.rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l{k}, Pose_net.regressor.{0,2}.{weight,bias}), data = DEVICE pointer
  * the gradient is WRITTEN to (same shape as the parameter), numel checked.  The forward is recomputed inside (nothing is
- * kept from odevio_ode_rnn_fwd).  Built so far: fixed-step solvers (rk4, rk4_classic, any ode_substeps) and tanh
- * nn.RNN; ODEVIO_ERR_UNSUPPORTED otherwise (adaptive solvers, nn.GRU, the Neural-CDE path). */
+ * kept from odevio_ode_rnn_fwd).  Fixed-step solvers (rk4, rk4_classic, any ode_substeps) are differentiated as they
+ * stand; for the adaptive ones (dopri5, tsit5, heun) the forward runs once more with a log of every ACCEPTED step
+ * size per row and interval, and those steps are replayed with their sizes held constant (one host read of the largest
+ * step count).  nn.RNN (tanh) and nn.GRU.  ODEVIO_ERR_UNSUPPORTED for the euler solver and the Neural-CDE path. */
 int odevio_ode_rnn_bwd(odevio_plan* plan, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
                        const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
                        const odevio_tensor* grads, int32_t n_grads, void* stream);

@@ -119,7 +119,7 @@ struct odevio_plan {
   bool status_pending = false;
   // backward (train.hip): plain and transposed copies of the ODEFunc / RNN / regressor weights, workspace
   TrainModel train = {};
-  DevBuf train_ws;
+  DevBuf train_ws, train_log;
   // Neural-CDE path (model_type cde)
   CdeModel cde = {};
   float *cde_init_w = nullptr, *cde_init_b = nullptr;
@@ -303,7 +303,7 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side, &p->train_ws})
+                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side, &p->train_ws, &p->train_log})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
@@ -632,12 +632,12 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       TRY(wt.get("Pose_net.rnn.weight_hh_l" + s, (int64_t)gates * F * F, whh));
       TRY(wt.get("Pose_net.rnn.bias_ih_l" + s, (int64_t)gates * F, bih));
       TRY(wt.get("Pose_net.rnn.bias_hh_l" + s, (int64_t)gates * F, bhh));
-      if (!gru) {   // plain copies for the backward (train.hip)
+      {   // plain copies for the backward (train.hip): [gates*F][F] and the transposes [F][gates*F]
         float *a = nullptr, *at = nullptr, *b2 = nullptr, *bt = nullptr, *c = nullptr, *d = nullptr;
         TRY(upload(p, &a, wih, st));
-        TRY(upload(p, &at, transposed(wih, F, F), st));
+        TRY(upload(p, &at, transposed(wih, gates * F, F), st));
         TRY(upload(p, &b2, whh, st));
-        TRY(upload(p, &bt, transposed(whh, F, F), st));
+        TRY(upload(p, &bt, transposed(whh, gates * F, F), st));
         TRY(upload(p, &c, bih, st));
         TRY(upload(p, &d, bhh, st));
         p->train.rnn_wih[l] = a; p->train.rnn_wih_t[l] = at; p->train.rnn_whh[l] = b2; p->train.rnn_whh_t[l] = bt;
@@ -1049,7 +1049,8 @@ static int launch_integ(odevio_plan* p, IntegArgs& a, int rt, size_t lds, hipStr
 }
 
 static int run_sequence(odevio_plan* p, const float* fused, const float* ts, const float* hc, int B, int P,
-                        float* out_seq, float* hT, int32_t* stats, hipStream_t st) {
+                        float* out_seq, float* hT, int32_t* stats, hipStream_t st, float* dtlog = nullptr, int* dtcnt = nullptr,
+                        int dtlog_cap = 0) {
   RoctxRange range("odevio: ODE + RNN (persistent integrator)");   // the reference's "ODE" and "RNN" ranges are one launch here
   const int L = p->cfg.rnn_num_layers;
   const int bpg_max = 8 / L;  // rows per group <= 8
@@ -1067,6 +1068,7 @@ static int run_sequence(odevio_plan* p, const float* fused, const float* ts, con
     a.B = B; a.P = P; a.b_begin = b0; a.b_end = b0 + nb;
     a.BPG = BPG; a.G = (nb + BPG - 1) / BPG; a.rows_per_group = R;
     a.fused = fused; a.ts = ts; a.ts_relative = hc ? 0 : 1; a.hc = hc; a.out_seq = out_seq; a.hT = hT; a.stats = stats;
+    a.dtlog = dtlog; a.dtcnt = dtcnt; a.dtlog_cap = dtlog_cap;
     if ((rc = launch_integ(p, a, rt, lds, st))) return rc;
   }
   return 0;
@@ -1367,29 +1369,35 @@ extern "C" int odevio_cde_fwd(odevio_plan* p, const float* obs, int32_t B, int32
 static int fill_train_model(odevio_plan* p, TrainModel& m) {
   const odevio_config& c = p->cfg;
   if (c.model_type == ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "backward: the Neural-CDE path has no backward yet");
-  if (c.rnn_type != ODEVIO_RNN_TANH) return fail(ODEVIO_ERR_UNSUPPORTED, "backward: nn.GRU is not built yet (tanh nn.RNN is)");
   m = p->train;
+  m.gru = c.rnn_type == ODEVIO_RNN_GRU;
   m.F = p->F; m.H = c.ode_hidden_dim; m.L = c.rnn_num_layers; m.act = c.ode_activation;
   m.with_ode = c.model_type == ODEVIO_MODEL_ODE_RNN;
   m.nlin = m.with_ode ? p->nlin : 0;
   for (int l = 0; l <= p->nlin; ++l) m.dims[l] = p->dims[l];
   for (int l = 0; l < p->nlin; ++l) m.ode_b[l] = p->ode_b[l];
   m.reg_w0 = p->reg_w0; m.reg_b0 = p->reg_b0; m.reg_w2 = p->reg_w2; m.reg_b2 = p->reg_b2;
-  m.stages = 1; m.nsub = 1;
+  m.stages = 1; m.jmax = 1; m.adaptive = 0; m.dtlog = nullptr; m.dtcnt = nullptr; m.dtlog_cap = 0;
   if (m.with_ode) {
-    if (!is_fixed_step(c.ode_solver))
-      return fail(ODEVIO_ERR_UNSUPPORTED, "backward: fixed-step solvers only for now (rk4, rk4_classic); adaptive solvers (replaying the "
-                                          "forward's accepted steps) are not built yet");
     IntegTableau t;
     fill_tableau(c.ode_solver, t);
-    m.stages = t.stages; m.nsub = c.ode_substeps;
+    if (!is_fixed_step(c.ode_solver)) {
+      if (!t.has_err)   // euler under torchode's controller: 1e-4 steps to the end (thousands per interval)
+        return fail(ODEVIO_ERR_UNSUPPORTED, "backward: the euler solver (dt0-sized steps without an error estimate) is not supported");
+      m.adaptive = 1;
+    }
+    // FSAL pairs: the last stage only feeds the error estimate (b_last = 0); the replay does not need it
+    m.stages = t.fsal ? t.stages - 1 : t.stages;
+    m.jmax = m.adaptive ? 0 : c.ode_substeps;   // adaptive: set by the caller from the forward's step log
     for (int i = 0; i < 8; ++i) {
-      m.b[i] = i < 7 ? t.b[i] : 0.f;
+      m.b[i] = i < m.stages ? t.b[i] : 0.f;
       for (int j = 0; j < 8; ++j) m.a[i][j] = (i < 7 && j < 7) ? t.a[i][j] : 0.f;
     }
   }
   return 0;
 }
+
+#define TRAIN_DTLOG_CAP 48   // accepted steps per row and interval the log holds (the reference's tolerances take 4-6)
 
 extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
                                   const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
@@ -1416,10 +1424,11 @@ extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const floa
     }
     for (int l = 0; l < m.L && want < 0; ++l) {
       const std::string sfx = "_l" + std::to_string(l);
-      if (nm == "Pose_net.rnn.weight_ih" + sfx) { g.rnn_wih[l] = dst; want = (int64_t)F * F; }
-      else if (nm == "Pose_net.rnn.weight_hh" + sfx) { g.rnn_whh[l] = dst; want = (int64_t)F * F; }
-      else if (nm == "Pose_net.rnn.bias_ih" + sfx) { g.rnn_bih[l] = dst; want = F; }
-      else if (nm == "Pose_net.rnn.bias_hh" + sfx) { g.rnn_bhh[l] = dst; want = F; }
+      const int64_t GF = (int64_t)(m.gru ? 3 : 1) * F;
+      if (nm == "Pose_net.rnn.weight_ih" + sfx) { g.rnn_wih[l] = dst; want = GF * F; }
+      else if (nm == "Pose_net.rnn.weight_hh" + sfx) { g.rnn_whh[l] = dst; want = GF * F; }
+      else if (nm == "Pose_net.rnn.bias_ih" + sfx) { g.rnn_bih[l] = dst; want = GF; }
+      else if (nm == "Pose_net.rnn.bias_hh" + sfx) { g.rnn_bhh[l] = dst; want = GF; }
     }
     if (want < 0) {
       if (nm == "Pose_net.regressor.0.weight") { g.reg_w0 = dst; want = (int64_t)128 * F; }
@@ -1430,6 +1439,24 @@ extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const floa
     if (want < 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_ode_rnn_bwd: '%s' is not a parameter of the pose path", nm.c_str());
     if (want != grads[i].numel)
       return fail(ODEVIO_ERR_BAD_ARG, "odevio_ode_rnn_bwd: gradient '%s' has %lld elements, expected %lld", nm.c_str(), (long long)grads[i].numel, (long long)want);
+  }
+  if (m.adaptive) {
+    // the forward once more on the persistent kernel, this time logging every accepted step size per row and interval;
+    // the host needs ONE number from it (the largest step count, which sizes the replay)
+    const int R = m.L * B;
+    const size_t n_log = (size_t)R * P * TRAIN_DTLOG_CAP, n_cnt = (size_t)R * P;
+    if ((rc = ensure(p->train_log, n_log + n_cnt + (size_t)R * F)) || (rc = ensure(p->out_seq, (size_t)B * P * F))) return rc;
+    float* dtlog = p->train_log.p;
+    int* dtcnt = reinterpret_cast<int*>(p->train_log.p + n_log);
+    float* hT_tmp = p->train_log.p + n_log + n_cnt;
+    HIPCHK(hipMemsetAsync(dtcnt, 0, n_cnt * sizeof(int), st));
+    if ((rc = run_sequence(p, fused, ts, hc_in, B, P, p->out_seq.p, hT_tmp, nullptr, st, dtlog, dtcnt, TRAIN_DTLOG_CAP))) return rc;
+    std::vector<int> cnt(n_cnt);
+    HIPCHK(hipMemcpyAsync(cnt.data(), dtcnt, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = odevio_check(p, stream))) return rc;     // a step budget / log overflow of that forward
+    m.jmax = std::max(1, *std::max_element(cnt.begin(), cnt.end()));
+    m.dtlog = dtlog; m.dtcnt = dtcnt; m.dtlog_cap = TRAIN_DTLOG_CAP;
   }
   if ((rc = ensure(p->train_ws, train_workspace_floats(m, B, P)))) return rc;
   rc = train_ode_rnn_bwd(m, p->train_ws.p, fused, ts, hc_in, B, P, grad_poses, grad_hT, grad_fused, grad_hc, g, st);

@@ -144,9 +144,10 @@ __global__ __launch_bounds__(256) void cde_hidden_kernel(CdeWhen wh, const float
 // youngest pieces have landed.  Past the last block the stream re-requests its last piece (unused) so that the counts
 // stay exact; nothing is ever requested outside the weight matrix.
 // BF16 = false: fp32 weights, the parity path.  BF16 = true (--dtype bf16 / fp16): the last layer stored as bf16 (half the
-// stream) and multiplied on the bf16 MFMA (v_mfma_f32_16x16x32_bf16: x rounded to bf16 once per launch, fp32
-// accumulation; 1/8 of the MFMA instructions, so the kernel stays a pure stream); bias, tanh, the contraction with
-// dX/dt, the state and the controller stay fp32.  Outside the 1e-4 claim (8 significant bits per operand).
+// stream) and multiplied on the bf16 MFMA (v_mfma_f32_16x16x32_bf16) against x held as two bf16 pieces, fp32
+// accumulation: 1/4 of the MFMA time of the fp32 path, so the kernel stays a pure stream (widening the weights to fp32
+// for the fp32 MFMA left it MFMA-bound: 500 us per evaluation against 356); bias, tanh, the contraction with dX/dt, the
+// state and the controller stay fp32.  Outside the 1e-4 claim (the weights carry 8 significant bits).
 // ---------------------------------------------------------------------------------------------------------------------
 #define CS_SLOTS 8
 #define CS_AHEAD 7
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ring is idle here): one coalesced round trip to L2 for the workgroup instead of NS dependent ones per lane.  Rows
     // past nb re-read row nb - 1: their MFMA columns are computed and never stored.
     f32x4 xv[BF16 ? 1 : NS];
-    bf16x8 xh[BF16 ? NS / 2 : 1];
+    bf16x8 xh[BF16 ? NS / 2 : 1], xl[BF16 ? NS / 2 : 1];
     {
       constexpr int XLD = H + 4;   // row stride in floats: the +4 spreads the 16 rows of a fragment read over the bank quads
       float* xs = reinterpret_cast<float*>(lds);
@@ -202,17 +203,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __syncthreads();
       // fp32 storage: fragment s covers k = 16 s + 4 q .. +3 (one 16-byte chunk of the row = 4 weights).
       // bf16 storage: a 16-byte chunk holds 8 weights = the 8 k-values one lane feeds to v_mfma_f32_16x16x32_bf16
-      // (k = 32 s + 8 q .. +7); x is rounded to bf16 once here (RNE) and kept as 8-element fragments xh[s].
+      // (k = 32 s + 8 q .. +7).  x is carried as TWO bf16 pieces x = xh + xl (16 significant bits, the residual exact):
+      // an x rounded to 8 bits differs from stage to stage of a Runge-Kutta step, which the adaptive solver's error
+      // estimate reads as error - measured: 49 instead of 20 steps per window with a single piece; rounded WEIGHTS are a
+      // consistent change of f and cost no steps.
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         if (BF16) {
           if (s < NS / 2) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(xs + r * XLD + 32 * s + 8 * q);
             const f32x4 b = *reinterpret_cast<const f32x4*>(xs + r * XLD + 32 * s + 8 * q + 4);
-            bf16x8 h;
+            bf16x8 h, l;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { h[j] = (__bf16)a[j]; h[4 + j] = (__bf16)b[j]; }
+            for (int j = 0; j < 4; ++j) {
+              h[j] = (__bf16)a[j]; h[4 + j] = (__bf16)b[j];
+              l[j] = (__bf16)(a[j] - (float)h[j]); l[4 + j] = (__bf16)(b[j] - (float)h[4 + j]);   // the residual is exact
+            }
             xh[s] = h;
+            xl[s] = l;
           }
         } else {
           xv[s] = *reinterpret_cast<const f32x4*>(xs + r * XLD + 16 * s + 4 * q);
@@ -282,8 +290,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (BF16) {
               // 8 bf16 weights per lane and read = one operand of the bf16 MFMA (K = 32 per instruction), fp32 accumulate
               const bf16x8 wh = __builtin_bit_cast(bf16x8, wv[st]);
-              if (st & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[4 * pc + st], acc1, 0, 0, 0);
-              else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[4 * pc + st], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[4 * pc + st], acc1, 0, 0, 0);   // low piece of x
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[4 * pc + st], acc0, 0, 0, 0);   // high piece
             } else {
               const f32x4 xs = xv[4 * pc + st];
               if (st & 1) {

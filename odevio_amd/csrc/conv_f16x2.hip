@@ -306,6 +306,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
+#if defined(ODEVIO_EXP_NODMA) || defined(ODEVIO_EXP_NOMFMA)
+  range_bad = false;   // timing experiments compute garbage by design
+#endif
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 }
 
@@ -330,6 +333,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16x2_kernel(ConvSplitArgs 
     if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), m, n, a.Cout, v);
     else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + m * (size_t)a.ld_out + n) = v;
   }
+#if defined(ODEVIO_EXP_NODMA) || defined(ODEVIO_EXP_NOMFMA)
+  range_bad = false;
+#endif
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 }
 

@@ -55,6 +55,12 @@ struct IntegArgs {
   const float* t1;                        // [rows]
   float* y_out;                           // [rows][F]
   int* stats;                             // [rows][2] or null
+  // accepted-step log for the backward (train.hip replays the forward's accepted steps): dtlog [rows][P][dtlog_cap] step
+  // sizes in order, dtcnt [rows][P] how many; null = no log.  More than dtlog_cap accepted steps in one interval raise the
+  // step-budget status.
+  float* dtlog;
+  int* dtcnt;
+  int dtlog_cap;
   // ---- infrastructure
   unsigned long long* xbuf;               // [G][2][xstride] 8-byte {tag, value} granules
   int xstride;

@@ -474,6 +474,8 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
       for (int j = 0; j < 7; ++j) k[j] = 0.f;
       bool have_k1 = false;
       int guard = 0;
+      int acc_it = 0;   // accepted steps of this row in this interval (logged for the backward)
+      const bool logger = a.dtlog && seq_mode && row_valid && owner && ocl == 0 && cu == 0;   // one thread per row
       while (__syncthreads_or((running && owner) ? 1 : 0)) {
         if (c.failed) break;
         if (++guard > a.max_steps) {
@@ -561,6 +563,11 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
         if (running) ++n_steps;
         if (upd) {
           ++n_acc;
+          if (logger) {
+            if (acc_it < a.dtlog_cap) a.dtlog[((size_t)grow * a.P + it) * a.dtlog_cap + acc_it] = dt;
+            else atomicCAS(c.status, 0, ST_MAX_STEPS);
+          }
+          ++acc_it;
           y = y1;
           if (a.tab.fsal) {
 #pragma unroll
@@ -579,6 +586,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
         }
         have_k1 = a.tab.fsal != 0;
       }
+      if (logger) a.dtcnt[(size_t)grow * a.P + it] = min(acc_it, a.dtlog_cap);
       if (!seq_mode) break;
     }
     if (!seq_mode || c.failed) break;

@@ -10,14 +10,21 @@
 // its own column-sharded layout.
 struct TrainModel {
   int F, H, nlin, act, L, with_ode;
+  int gru;                // 0: tanh nn.RNN; 1: nn.GRU (gate order r, z, n: weights [3F][F], biases [3F])
   int dims[TRAIN_MAX_LIN + 1];
   const float *ode_w[TRAIN_MAX_LIN], *ode_w_t[TRAIN_MAX_LIN], *ode_b[TRAIN_MAX_LIN];
   const float *rnn_wih[TRAIN_MAX_L], *rnn_wih_t[TRAIN_MAX_L], *rnn_whh[TRAIN_MAX_L], *rnn_whh_t[TRAIN_MAX_L];
   const float *rnn_bih[TRAIN_MAX_L], *rnn_bhh[TRAIN_MAX_L];
   const float *reg_w0, *reg_w0_t, *reg_b0, *reg_w2, *reg_b2;
-  // fixed-step tableau
-  int stages, nsub;
+  // tableau (for FSAL pairs the last stage, which only feeds the error estimate, is left out) and steps per interval:
+  // fixed-step solvers take `jmax` = ode_substeps equal steps; adaptive ones replay the forward's ACCEPTED steps from the
+  // integrator's log (dtlog [rows][P][dtlog_cap], dtcnt [rows][P]); rows with fewer than `jmax` steps in an interval
+  // take zero-length steps for the rest, which change nothing and carry no gradient
+  int stages, jmax, adaptive;
   float a[8][8], b[8];
+  const float* dtlog;
+  const int* dtcnt;
+  int dtlog_cap;
 };
 
 // Where the weight gradients go (device pointers, same shapes as the reference's parameters; null = not wanted).

@@ -15,9 +15,10 @@
 //      to first), writing the pre-activation gradients into delta[l] [M, dims[l+1]];
 //   3. WEIGHT GRADIENTS as ONE GEMM per weight: dW_l = delta[l]^T act[l] (contraction over all M rows at once: the
 //      rank-R updates of a step-by-step formulation become a single [N, M] x [M, K] product), biases = column sums.
-// Supported now: fixed-step solvers (rk4 = 3/8 rule, rk4_classic; any ode_substeps), tanh nn.RNN, every ODEFunc
-// activation, cat / soft fusion handled by the caller (the gradient is returned w.r.t. the FUSED features).
-// Adaptive solvers (replaying the accepted step sequence of the forward) and nn.GRU: next.
+// Supported now: fixed-step solvers (rk4 = 3/8 rule, rk4_classic; any ode_substeps) and the adaptive ones (dopri5, tsit5,
+// heun: the forward's ACCEPTED steps are replayed from the integrator's log, their sizes treated as constants of the
+// differentiation), tanh nn.RNN and nn.GRU, every ODEFunc activation; fusion is the caller's (the gradient is returned
+// w.r.t. the FUSED features).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -131,12 +132,19 @@ __device__ __forceinline__ float tr_act_grad(float a, int act) {
 
 __global__ void act_kernel(float* x, size_t n, int act) { EW_LOOP(i, n) x[i] = tr_act(x[i], act); }
 
-// dt[i][r] = (ts[b][i+1] - ts[b][i]) / nsub with b = r % B (the relative shift of PoseODERNN.py:100 cancels in the difference)
-__global__ void dt_rows_kernel(const float* __restrict__ ts, float* __restrict__ dt, int B, int P, int R, int nsub) {
-  EW_LOOP(i, (size_t)P * R) {
-    const int it = (int)(i / R), b = (int)(i % R) % B;
-    const float* tr = ts + (size_t)b * (P + 1);
-    dt[i] = (tr[it + 1] - tr[it]) / (float)nsub;
+// dt[it][j][r]: fixed-step solvers: (ts[b][it+1] - ts[b][it]) / J with b = r % B (the relative shift of PoseODERNN.py:100
+// cancels in the difference); adaptive solvers: the j-th ACCEPTED step of row r in interval it from the forward's log, or
+// 0 once the row has reached the end of the interval
+__global__ void dt_rows_kernel(const float* __restrict__ ts, float* __restrict__ dt, int B, int P, int R, int J,
+                               const float* __restrict__ dtlog, const int* __restrict__ dtcnt, int cap) {
+  EW_LOOP(i, (size_t)P * J * R) {
+    const int r = (int)(i % R), j = (int)((i / R) % J), it = (int)(i / ((size_t)R * J));
+    if (dtlog) {
+      dt[i] = j < dtcnt[(size_t)r * P + it] ? dtlog[((size_t)r * P + it) * cap + j] : 0.f;
+    } else {
+      const float* tr = ts + (size_t)(r % B) * (P + 1);
+      dt[i] = (tr[it + 1] - tr[it]) / (float)J;
+    }
   }
 }
 
@@ -186,6 +194,46 @@ __global__ void rnn_cell_bwd_kernel(const float* __restrict__ g, const float* __
   EW_LOOP(i, n) {
     const float gg = g[i] + (g2 ? g2[i] : 0.f);
     delta[i] = gg * (1.f - hn[i] * hn[i]);
+  }
+}
+// nn.GRU cell (gate order r, z, n): gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh, both [B][3F];
+//   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) n + z h
+// gates [B][4F] keeps (r, z, n, gh_n) for the backward
+__device__ __forceinline__ float tr_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+__global__ void gru_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hp,
+                                float* __restrict__ gates, float* __restrict__ hn, float* __restrict__ ynew, int B, int F) {
+  EW_LOOP(i, (size_t)B * F) {
+    const size_t b = i / F, c = i % F;
+    const float* gib = gi + b * 3 * F;
+    const float* ghb = gh + b * 3 * F;
+    const float r = tr_sigmoid(gib[c] + ghb[c]);
+    const float z = tr_sigmoid(gib[F + c] + ghb[F + c]);
+    const float ghn = ghb[2 * F + c];
+    const float n = tanhf(gib[2 * F + c] + r * ghn);
+    const float v = (1.f - z) * n + z * hp[i];
+    float* gt = gates + b * 4 * F;
+    gt[c] = r; gt[F + c] = z; gt[2 * F + c] = n; gt[3 * F + c] = ghn;
+    hn[i] = v;
+    ynew[i] = v;
+  }
+}
+// g = dL/dh' -> delta_i [B][3F] (w.r.t. gi), delta_h [B][3F] (w.r.t. gh), dhp_direct [B][F] = g * z
+__global__ void gru_cell_bwd_kernel(const float* __restrict__ g, const float* __restrict__ g2, const float* __restrict__ gates,
+                                    const float* __restrict__ hp, float* __restrict__ di, float* __restrict__ dh,
+                                    float* __restrict__ dhp_direct, int B, int F) {
+  EW_LOOP(i, (size_t)B * F) {
+    const size_t b = i / F, c = i % F;
+    const float* gt = gates + b * 4 * F;
+    const float r = gt[c], z = gt[F + c], n = gt[2 * F + c], ghn = gt[3 * F + c];
+    const float gg = g[i] + (g2 ? g2[i] : 0.f);
+    const float dn_pre = gg * (1.f - z) * (1.f - n * n);
+    const float dz_pre = gg * (hp[i] - n) * z * (1.f - z);
+    const float dr_pre = dn_pre * ghn * r * (1.f - r);
+    float* dib = di + b * 3 * F;
+    float* dhb = dh + b * 3 * F;
+    dib[c] = dr_pre; dib[F + c] = dz_pre; dib[2 * F + c] = dn_pre;
+    dhb[c] = dr_pre; dhb[F + c] = dz_pre; dhb[2 * F + c] = dn_pre * r;
+    dhp_direct[i] = gg * z;
   }
 }
 __global__ void add_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n) { EW_LOOP(i, n) x[i] += y[i]; }
@@ -266,16 +314,18 @@ int train_pose_loss(const float* poses, const float* gts, int M, float* loss3, f
 // ---------------------------------------------------------------------------------------------------------------------
 size_t train_workspace_floats(const TrainModel& m, int B, int P) {
   const int R = m.L * B, S = m.stages;
-  const size_t M = (size_t)P * m.nsub * S * R, MB = (size_t)P * B;
+  const size_t M = (size_t)P * m.jmax * S * R, MB = (size_t)P * B;
   size_t n = 0;
   for (int l = 0; l <= m.nlin; ++l) n += M * m.dims[l];          // act
   for (int l = 0; l < m.nlin; ++l) n += M * m.dims[l + 1];       // delta
-  n += ((size_t)P * R + 3) / 4 * 4;                              // dt (kept 16-byte aligned: the GEMM operands behind it are read as float4)
+  n += ((size_t)P * m.jmax * R + 3) / 4 * 4;                     // dt (kept 16-byte aligned: the GEMM operands behind it are read as float4)
   n += 3 * (size_t)R * m.F;                                      // Y, lam, gX
   n += 8 * (size_t)R * m.F;                                      // lamK
   n += (size_t)R * std::max(m.F, m.H);                           // scratch g
-  n += (size_t)m.L * MB * m.F * 4;                               // rnn_in, rnn_hp, rnn_out, rnn_delta
-  n += 4 * (size_t)B * m.F;                                      // gi, gh, dinp, dhp
+  const size_t G = m.gru ? 3 : 1;
+  n += (size_t)m.L * MB * m.F * (3 + G);                         // rnn_in, rnn_hp, rnn_out, rnn_delta (GRU: [MB][3F])
+  if (m.gru) n += (size_t)m.L * MB * m.F * (3 + 4);              // GRU: delta w.r.t. gh [MB][3F], gates [MB][4F]
+  n += (2 * G + 3) * (size_t)B * m.F;                            // gi, gh ([B][G*F] each), dinp, dhp, dhp_direct
   n += MB * 128 * 2 + (MB * 6 + 3) / 4 * 4 + MB * m.F;           // hid, dhid, dposes (interval-major), dout
   return n;
 }
@@ -284,25 +334,33 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
                       const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc, const TrainGrads& g,
                       hipStream_t st) {
   const int L = m.L, F = m.F, R = L * B, S = m.stages, nl = m.nlin;
-  const size_t M = (size_t)P * m.nsub * S * R, MB = (size_t)P * B, RF = (size_t)R * F;
+  const int J = m.jmax;
+  const size_t M = (size_t)P * J * S * R, MB = (size_t)P * B, RF = (size_t)R * F;
   // ---- carve the workspace
   float* q = ws;
   float* act[TRAIN_MAX_LIN + 1];
   float* delta[TRAIN_MAX_LIN];
   for (int l = 0; l <= nl; ++l) { act[l] = q; q += M * m.dims[l]; }
   for (int l = 0; l < nl; ++l) { delta[l] = q; q += M * m.dims[l + 1]; }
-  float* dt = q; q += ((size_t)P * R + 3) / 4 * 4;
+  float* dt = q; q += ((size_t)P * J * R + 3) / 4 * 4;
   float* Y = q; q += RF;
   float* lam = q; q += RF;
   float* gX = q; q += RF;
   float* lamK = q; q += 8 * RF;
   float* gs = q; q += (size_t)R * std::max(F, m.H);
+  const int G = m.gru ? 3 : 1, GF = G * F;     // gate rows per hidden unit
   float *rnn_in[TRAIN_MAX_L], *rnn_hp[TRAIN_MAX_L], *rnn_out[TRAIN_MAX_L], *rnn_delta[TRAIN_MAX_L];
-  for (int l = 0; l < L; ++l) { rnn_in[l] = q; q += MB * F; rnn_hp[l] = q; q += MB * F; rnn_out[l] = q; q += MB * F; rnn_delta[l] = q; q += MB * F; }
-  float* gi = q; q += (size_t)B * F;
-  float* gh = q; q += (size_t)B * F;
+  float *rnn_delta_h[TRAIN_MAX_L] = {}, *rnn_gates[TRAIN_MAX_L] = {};
+  for (int l = 0; l < L; ++l) {
+    rnn_in[l] = q; q += MB * F; rnn_hp[l] = q; q += MB * F; rnn_out[l] = q; q += MB * F; rnn_delta[l] = q; q += MB * GF;
+    if (m.gru) { rnn_delta_h[l] = q; q += MB * GF; rnn_gates[l] = q; q += MB * 4 * F; }
+    else rnn_delta_h[l] = rnn_delta[l];      // tanh RNN: one delta serves W_ih and W_hh
+  }
+  float* gi = q; q += (size_t)B * GF;
+  float* gh = q; q += (size_t)B * GF;
   float* dinp = q; q += (size_t)B * F;
   float* dhp = q; q += (size_t)B * F;
+  float* dhp_direct = q; q += (size_t)B * F;
   float* hid = q; q += MB * 128;
   float* dhid = q; q += MB * 128;
   float* dpo = q; q += (MB * 6 + 3) / 4 * 4;
@@ -317,17 +375,18 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
   for (int j = 0; j < 8; ++j) brow.c[j] = j < S ? m.b[j] : 0.f;
 
   // =============================== 1. tape ===============================
-  hipLaunchKernelGGL(dt_rows_kernel, EW_GRID((size_t)P * R), 0, st, ts, dt, B, P, R, m.nsub);
+  hipLaunchKernelGGL(dt_rows_kernel, EW_GRID((size_t)P * J * R), 0, st, ts, dt, B, P, R, J, m.adaptive ? m.dtlog : nullptr, m.dtcnt, m.dtlog_cap);
   if (hc) (void)hipMemcpyAsync(Y, hc, RF * sizeof(float), hipMemcpyDeviceToDevice, st);
   else (void)hipMemsetAsync(Y, 0, RF * sizeof(float), st);
   for (int it = 0; it < P; ++it) {
     if (m.with_ode) {
-      for (int j = 0; j < m.nsub; ++j) {
-        const size_t mstep = ((size_t)it * m.nsub + j) * S * R;             // first tape row of this step
+      for (int j = 0; j < J; ++j) {
+        const float* dtp = dt + ((size_t)it * J + j) * R;                   // this step's size, per row
+        const size_t mstep = ((size_t)it * J + j) * S * R;                  // first tape row of this step
         const float* kbase = act[nl] + mstep * F;                           // K_0 of this step; K_s is S*... rows later
         for (int s = 0; s < S; ++s) {
           const size_t m0 = mstep + (size_t)s * R;
-          hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, act[0] + m0 * F, Y, kbase, RF, arow[s], dt + (size_t)it * R, R, F);
+          hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, act[0] + m0 * F, Y, kbase, RF, arow[s], dtp, R, F);
           for (int l = 0; l < nl; ++l) {
             float* o = act[l + 1] + m0 * m.dims[l + 1];
             gemm_nt(st, act[l] + m0 * m.dims[l], m.dims[l], m.ode_w[l], m.dims[l], m.ode_b[l], o, m.dims[l + 1], R, m.dims[l + 1], m.dims[l]);
@@ -335,7 +394,7 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
           }
         }
         // Y <- Y + dt * sum_s b_s K_s: the stage-input formula with the b row
-        hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, Y, Y, kbase, RF, brow, dt + (size_t)it * R, R, F);
+        hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, Y, Y, kbase, RF, brow, dtp, R, F);
       }
     }
     for (int l = 0; l < L; ++l) {
@@ -345,9 +404,13 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
       if (l == 0) hipLaunchKernelGGL(gather_interval_kernel, EW_GRID((size_t)B * F), 0, st, fused, in_l, B, P, F, it);
       else (void)hipMemcpyAsync(in_l, rnn_out[l - 1] + (size_t)it * B * F, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);
       (void)hipMemcpyAsync(hp_l, Y + (size_t)l * B * F, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);
-      gemm_nt(st, in_l, F, m.rnn_wih[l], F, m.rnn_bih[l], gi, F, B, F, F);
-      gemm_nt(st, hp_l, F, m.rnn_whh[l], F, m.rnn_bhh[l], gh, F, B, F, F);
-      hipLaunchKernelGGL(rnn_cell_kernel, EW_GRID((size_t)B * F), 0, st, gi, gh, out_l, Y + (size_t)l * B * F, (size_t)B * F);
+      gemm_nt(st, in_l, F, m.rnn_wih[l], F, m.rnn_bih[l], gi, GF, B, GF, F);
+      gemm_nt(st, hp_l, F, m.rnn_whh[l], F, m.rnn_bhh[l], gh, GF, B, GF, F);
+      if (m.gru)
+        hipLaunchKernelGGL(gru_cell_kernel, EW_GRID((size_t)B * F), 0, st, gi, gh, hp_l, rnn_gates[l] + (size_t)it * B * 4 * F, out_l,
+                           Y + (size_t)l * B * F, B, F);
+      else
+        hipLaunchKernelGGL(rnn_cell_kernel, EW_GRID((size_t)B * F), 0, st, gi, gh, out_l, Y + (size_t)l * B * F, (size_t)B * F);
     }
   }
   // regressor hidden layer on the top-layer outputs (interval-major rows)
@@ -364,19 +427,26 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
     // lam = dL/d(state after the RNN of interval it); the top layer's output also feeds the regressor
     hipLaunchKernelGGL(add_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)(L - 1) * B * F, dout + (size_t)it * B * F, (size_t)B * F);
     for (int l = L - 1; l >= 0; --l) {
-      float* d_l = rnn_delta[l] + (size_t)it * B * F;
+      float* d_l = rnn_delta[l] + (size_t)it * B * GF;
+      float* dh_l = rnn_delta_h[l] + (size_t)it * B * GF;
       // gradient reaching hn_l: its own state slot, plus (below the top) what the layer above sent down its input
-      hipLaunchKernelGGL(rnn_cell_bwd_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)l * B * F, l + 1 < L ? dinp : nullptr,
-                         rnn_out[l] + (size_t)it * B * F, d_l, (size_t)B * F);
-      gemm_nt(st, d_l, F, m.rnn_wih_t[l], F, nullptr, dinp, F, B, F, F);                 // d input  = delta W_ih
-      gemm_nt(st, d_l, F, m.rnn_whh_t[l], F, nullptr, dhp, F, B, F, F);                  // d hidden = delta W_hh
+      if (m.gru)
+        hipLaunchKernelGGL(gru_cell_bwd_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)l * B * F, l + 1 < L ? dinp : nullptr,
+                           rnn_gates[l] + (size_t)it * B * 4 * F, rnn_hp[l] + (size_t)it * B * F, d_l, dh_l, dhp_direct, B, F);
+      else
+        hipLaunchKernelGGL(rnn_cell_bwd_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)l * B * F, l + 1 < L ? dinp : nullptr,
+                           rnn_out[l] + (size_t)it * B * F, d_l, (size_t)B * F);
+      gemm_nt(st, d_l, GF, m.rnn_wih_t[l], GF, nullptr, dinp, F, B, F, GF);               // d input  = delta_i W_ih
+      gemm_nt(st, dh_l, GF, m.rnn_whh_t[l], GF, nullptr, dhp, F, B, F, GF);              // d hidden = delta_h W_hh
+      if (m.gru) hipLaunchKernelGGL(add_kernel, EW_GRID((size_t)B * F), 0, st, dhp, dhp_direct, (size_t)B * F);   // + g * z
       (void)hipMemcpyAsync(lam + (size_t)l * B * F, dhp, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);   // -> d evolved state
       if (l == 0 && grad_fused) hipLaunchKernelGGL(scatter_interval_kernel, EW_GRID((size_t)B * F), 0, st, dinp, grad_fused, B, P, F, it);
     }
     if (m.with_ode) {
-      for (int j = m.nsub - 1; j >= 0; --j) {
-        const size_t mstep = ((size_t)it * m.nsub + j) * S * R;
-        hipLaunchKernelGGL(step_adjoint_init_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, brow, dt + (size_t)it * R, R, F);
+      for (int j = J - 1; j >= 0; --j) {
+        const float* dtp = dt + ((size_t)it * J + j) * R;
+        const size_t mstep = ((size_t)it * J + j) * S * R;
+        hipLaunchKernelGGL(step_adjoint_init_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, brow, dtp, R, F);
         for (int s = S - 1; s >= 0; --s) {
           const size_t m0 = mstep + (size_t)s * R;
           // K_s = tanh(.) : delta of the last Linear
@@ -387,7 +457,7 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
                                (size_t)R * m.dims[l], m.act);
           }
           gemm_nt(st, delta[0] + m0 * m.dims[1], m.dims[1], m.ode_w_t[0], m.dims[1], nullptr, gX, F, R, F, m.dims[1]);
-          hipLaunchKernelGGL(stage_adjoint_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, gX, arow[s], dt + (size_t)it * R, R, F);
+          hipLaunchKernelGGL(stage_adjoint_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, gX, arow[s], dtp, R, F);
         }
       }
     }
@@ -402,10 +472,10 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
     }
   }
   for (int l = 0; l < L; ++l) {
-    if (g.rnn_wih[l]) gemm_tn(st, rnn_delta[l], F, rnn_in[l], F, g.rnn_wih[l], F, (int)MB, F, F);
-    if (g.rnn_whh[l]) gemm_tn(st, rnn_delta[l], F, rnn_hp[l], F, g.rnn_whh[l], F, (int)MB, F, F);
-    if (g.rnn_bih[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(F), 0, st, rnn_delta[l], g.rnn_bih[l], (int)MB, F);
-    if (g.rnn_bhh[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(F), 0, st, rnn_delta[l], g.rnn_bhh[l], (int)MB, F);
+    if (g.rnn_wih[l]) gemm_tn(st, rnn_delta[l], GF, rnn_in[l], F, g.rnn_wih[l], F, (int)MB, GF, F);
+    if (g.rnn_whh[l]) gemm_tn(st, rnn_delta_h[l], GF, rnn_hp[l], F, g.rnn_whh[l], F, (int)MB, GF, F);
+    if (g.rnn_bih[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(GF), 0, st, rnn_delta[l], g.rnn_bih[l], (int)MB, GF);
+    if (g.rnn_bhh[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(GF), 0, st, rnn_delta_h[l], g.rnn_bhh[l], (int)MB, GF);
   }
   if (g.reg_w0) gemm_tn(st, dhid, 128, rnn_out[L - 1], F, g.reg_w0, F, (int)MB, 128, F);
   if (g.reg_b0) hipLaunchKernelGGL(colsum_kernel, EW_GRID(128), 0, st, dhid, g.reg_b0, (int)MB, 128);

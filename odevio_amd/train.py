@@ -5,7 +5,8 @@ The reference trains with plain autograd (scripts/train_model.py:69-78): ``poses
 through the solver's own arithmetic.  Here the same chain is two ``torch.autograd.Function``s whose forward AND backward
 run in libodevio (``odevio_ode_rnn_fwd`` / ``odevio_ode_rnn_bwd``, ``odevio_pose_loss``); PyTorch only carries the graph.
 
-First slice (what ``odevio_ode_rnn_bwd`` covers): fixed-step solvers (rk4, rk4_classic), tanh ``nn.RNN``, ``cat`` fusion;
+What ``odevio_ode_rnn_bwd`` covers: fixed-step solvers (rk4, rk4_classic) and adaptive ones (dopri5, tsit5, heun: the
+forward's accepted steps are replayed, their sizes held constant), ``nn.RNN`` and ``nn.GRU``, ``cat`` fusion;
 gradients reach the encoder FEATURES (fv, fi), the carried state ``hc`` and every parameter of ``Pose_net``
 (ODEFunc, RNN, regressor).  The encoders' own backward is not built yet.
 """

@@ -240,12 +240,14 @@ def rk_stages(f, tab, y, dt, k1=None):
     return y1, err, ks[-1]
 
 
-def evolve_state(f, y0, t0, t1, method, substeps=1, atol=ATOL, rtol=RTOL, dt0=DT0, trace=None):
+def evolve_state(f, y0, t0, t1, method, substeps=1, atol=ATOL, rtol=RTOL, dt0=DT0, trace=None, detach_controller=False):
     """Solve dy/dt = f(y) from per-row ``t0`` to ``t1`` (PoseODERNN.py:70-75 + DESIGN.md section 3).
 
     Rows are independent (own t, dt, accept flag), exactly as in torchode.  ``method`` in the
     reference's set uses the adaptive I-controller; ``rk4``/``rk4_classic`` take ``substeps`` equal
     steps.  ``trace`` (optional dict) receives per-row step counts and the dt sequence.
+    ``detach_controller=True`` (gradient reference of the backward tests): the step sizes the controller picks are
+    constants of the differentiation - autograd then differentiates the accepted steps as they were taken.
     """
     tab = TABLEAUX[method]
     R = y0.shape[0]
@@ -279,11 +281,13 @@ def evolve_state(f, y0, t0, t1, method, substeps=1, atol=ATOL, rtol=RTOL, dt0=DT
             raise RuntimeError("evolve_state: step budget exhausted")
         y1, err, klast = rk_stages(f, tab, y, dt, k1)
         if err is not None:
-            bound = atol + rtol * torch.maximum(y.abs(), y1.abs())
-            ratio = torch.sqrt(torch.mean((err / bound) ** 2, dim=1))
-            accept = ratio < 1.0
-            factor = torch.clamp(SAFETY * ratio ** (-1.0 / tab.order), FACTOR_MIN, FACTOR_MAX)
-            dt_next = dt * factor
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not detach_controller):
+                ye, y1e, ee = (y.detach(), y1.detach(), err.detach()) if detach_controller else (y, y1, err)
+                bound = atol + rtol * torch.maximum(ye.abs(), y1e.abs())
+                ratio = torch.sqrt(torch.mean((ee / bound) ** 2, dim=1))
+                accept = ratio < 1.0
+                factor = torch.clamp(SAFETY * ratio ** (-1.0 / tab.order), FACTOR_MIN, FACTOR_MAX)
+                dt_next = dt * factor
         else:
             accept = torch.ones(R, dtype=torch.bool)
             dt_next = dt.clone()
@@ -344,7 +348,7 @@ def regressor(sd, x):
     return F_.linear(y, sd["Pose_net.regressor.2.weight"], sd["Pose_net.regressor.2.bias"])
 
 
-def pose_ode_rnn(sd, fv, fi, ts, prev, opt, dtype=torch.float32, trace=None, with_ode=True):
+def pose_ode_rnn(sd, fv, fi, ts, prev, opt, dtype=torch.float32, trace=None, with_ode=True, detach_controller=False):
     """PoseODERNN.forward (PoseODERNN.py:88-123); ``with_ode=False`` gives PoseRNN.forward (PoseRNN.py:53-73)."""
     sd = _sd(sd, dtype)
     fused = fuse(sd, fv, fi, opt.fuse_method, dtype)
@@ -363,7 +367,8 @@ def pose_ode_rnn(sd, fv, fi, ts, prev, opt, dtype=torch.float32, trace=None, wit
             t0 = ts_diff[:, i].repeat(L)
             t1 = ts_diff[:, i + 1].repeat(L)
             tr = {} if trace is not None else None
-            rows = evolve_state(f, rows, t0, t1, opt.ode_solver, getattr(opt, "ode_substeps", 1), trace=tr)
+            rows = evolve_state(f, rows, t0, t1, opt.ode_solver, getattr(opt, "ode_substeps", 1), trace=tr,
+                                detach_controller=detach_controller)
             if trace is not None:
                 trace.setdefault("intervals", []).append(tr)
             h = rows.reshape(L, B, Fdim)

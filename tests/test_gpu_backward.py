@@ -16,12 +16,13 @@ pytestmark = pytest.mark.gpu
 GTOL = 1e-3
 
 
-def _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names):
-    leaves = {k: v.clone().double().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
-    fv64, fi64 = fv.double().requires_grad_(True), fi.double().requires_grad_(True)
-    hc64 = None if hc is None else hc.double().requires_grad_(True)
+def _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names, dtype=torch.float64):
+    leaves = {k: v.clone().to(dtype).requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    fv64, fi64 = fv.to(dtype).requires_grad_(True), fi.to(dtype).requires_grad_(True)
+    hc64 = None if hc is None else hc.to(dtype).requires_grad_(True)
     with_ode = opt.model_type == "ode-rnn"
-    poses, h_T = oc.pose_ode_rnn(leaves, fv64, fi64, ts, hc64, opt, dtype=torch.float64, with_ode=with_ode)
+    # the step sizes an adaptive controller picked are constants of the differentiation (the backward replays the accepted steps)
+    poses, h_T = oc.pose_ode_rnn(leaves, fv64, fi64, ts, hc64, opt, dtype=dtype, with_ode=with_ode, detach_controller=True)
     loss = 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3].double()) + \
         torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:].double())
     loss.backward()
@@ -39,6 +40,8 @@ def _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names):
     dict(ode_solver="rk4", rnn_num_layers=3, ode_activation_fn="softplus", ode_fn_num_layers=2, ode_hidden_dim=1024),  # the reference recipe's shapes
     dict(ode_solver="rk4", ode_activation_fn="relu", rnn_num_layers=1),
     dict(model_type="rnn"),
+    dict(ode_solver="rk4", ode_rnn_type="gru"),
+    dict(model_type="rnn", ode_rnn_type="gru", rnn_num_layers=3),
 ])
 @pytest.mark.parametrize("with_hc", [False, True])
 def test_ode_rnn_backward_matches_autograd_through_the_oracle(cfg, with_hc):
@@ -72,13 +75,49 @@ def test_ode_rnn_backward_matches_autograd_through_the_oracle(cfg, with_hc):
     assert not bad, f"gradients off by more than {GTOL}: {bad}"
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(ode_solver="dopri5"),
+    dict(ode_solver="dopri5", rnn_num_layers=3, ode_activation_fn="softplus", ode_fn_num_layers=2, ode_hidden_dim=1024),  # the reference's training recipe (scripts/run_training.sh:6-28)
+    dict(ode_solver="tsit5", ode_rnn_type="gru"),
+    dict(ode_solver="heun"),
+])
+def test_adaptive_solver_backward_replays_the_accepted_steps(cfg):
+    """Adaptive solvers: the backward replays the ACCEPTED steps of the forward (logged by the integrator kernel) with
+    their sizes held constant.  Reference: autograd through the oracle in fp32 with the controller detached - fp32 so
+    that both sides take the same step decisions (tests/test_gpu_parity.py pins the step sequences); a sequence that
+    differs in a borderline accept/reject would change the gradient at the tolerance's own level (rtol 1e-2)."""
+    opt = default_opt(img_h=64, img_w=128, **cfg)
+    model, sd = make_model(opt, seed=73)
+    B, P, L, F = 3, 4, opt.rnn_num_layers, 768
+    g = torch.Generator().manual_seed(6)
+    fv, fi = torch.randn(B, P, 512, generator=g), torch.randn(B, P, 256, generator=g)
+    ts = synth.timestamps(B, P + 1, drop=0.4, seed=4, absolute=True)
+    hc = torch.randn(L, B, F, generator=g) * 0.3
+    gts = torch.randn(B, P, 6, generator=g) * torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    names = train.pose_param_names(opt)
+    ref = _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names, dtype=torch.float32)
+    fv_d, fi_d, hc_d = fv.cuda().requires_grad_(True), fi.cuda().requires_grad_(True), hc.cuda().requires_grad_(True)
+    poses, h_T = train.pose_net(model, fv_d, fi_d, ts.cuda(), hc_d)
+    train.pose_loss(poses, gts.cuda()).backward()
+    model.check()
+    assert oc.rel_err(poses, ref["poses"]) < 1e-4
+    errs = {"fv": oc.rel_err(fv_d.grad, ref["fv"]), "fi": oc.rel_err(fi_d.grad, ref["fi"]), "hc": oc.rel_err(hc_d.grad, ref["hc"])}
+    params = dict(model.named_parameters())
+    for n in names:
+        errs[n] = oc.rel_err(params[n].grad, ref[n])
+    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v < GTOL}
+    assert not bad, f"gradients off by more than {GTOL}: {bad}"
+
+
 def test_backward_refuses_what_is_not_built():
-    opt = default_opt(img_h=64, img_w=128, ode_solver="dopri5")
+    opt = default_opt(img_h=64, img_w=128, ode_solver="euler")
     model, _ = make_model(opt, seed=72)
     fv, fi = torch.randn(2, 3, 512).cuda().requires_grad_(True), torch.randn(2, 3, 256).cuda()
-    poses, _ = train.pose_net(model, fv, fi, synth.timestamps(2, 4).cuda())
-    with pytest.raises(ValueError, match="fixed-step"):
+    ts = torch.tensor([[0.0, 0.001, 0.002, 0.003]]).repeat(2, 1)      # euler takes 1e-4 steps: keep the forward short
+    poses, _ = train.pose_net(model, fv, fi, ts.cuda())
+    with pytest.raises(ValueError, match="euler"):
         poses.sum().backward()
+
     with pytest.raises(ValueError):
         train.pose_net(make_model(default_opt(img_h=64, img_w=128, fuse_method="soft"), seed=1)[0], fv, fi, synth.timestamps(2, 4).cuda())
 
