@@ -159,12 +159,16 @@ static int upload(odevio_plan* p, float** out, const std::vector<float>& h, hipS
   HIPCHK(hipStreamSynchronize(st));  // h may be a temporary
   return 0;
 }
+// Every plan buffer is followed, inside its allocation, by ODEVIO_ZERO_PAGE_BYTES zero bytes (at b.p + b.n): the conv
+// kernels' 32-bit DMA addressing reads them for taps outside the image (common.h, ConvSplitArgs::in_zero_off).  Nothing
+// ever writes there: every kernel's extent is b.n.
 static int ensure(DevBuf& b, size_t n) {
   if (b.n >= n) return 0;
   if (b.p) HIPCHK(hipFree(b.p));
   b.p = nullptr;
   b.n = 0;
-  HIPCHK(hipMalloc((void**)&b.p, n * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&b.p, n * sizeof(float) + ODEVIO_ZERO_PAGE_BYTES));
+  HIPCHK(hipMemset(b.p + n, 0, ODEVIO_ZERO_PAGE_BYTES));
   b.n = n;
   return 0;
 }
@@ -186,6 +190,18 @@ static std::vector<float> transposed(const std::vector<float>& w, int N, int K) 
   for (int n = 0; n < N; ++n)
     for (int k = 0; k < K; ++k) t[(size_t)k * N + n] = w[(size_t)n * K + k];
   return t;
+}
+
+// 32-bit DMA addressing (conv_f16x2.hip) when `in` lies in a plan buffer (whose zero tail follows it) and everything is
+// below 4 GB; the weights always carry their tail.
+static void set_off32(const odevio_plan* p, ConvSplitArgs& a, const void* in) {
+  const size_t ext = extent_of(p, in, 0);
+  a.off32 = 0;
+  static const bool off64 = getenv("ODEVIO_CONV_OFF64") != nullptr;   // diagnostic: the 64-bit addressing form
+  if (off64 || ext == 0 || ext + ODEVIO_ZERO_PAGE_BYTES > 0xffffffffull || a.w_bytes + ODEVIO_ZERO_PAGE_BYTES > 0xffffffffull) return;
+  a.in_zero_off = (unsigned)ext;
+  a.w_zero_off = (unsigned)a.w_bytes;
+  a.off32 = 1;
 }
 
 struct WeightTable {
@@ -447,6 +463,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       std::vector<uint16_t> ws;
       prescale = split_conv_weights(w, cs.cout, cs.cin, cs.k * cs.k, ws);
       p->conv_ws_bytes[i] = ws.size() * sizeof(uint16_t);
+      ws.resize(ws.size() + ODEVIO_ZERO_PAGE_BYTES / sizeof(uint16_t), 0);   // zero tail (32-bit DMA addressing)
       TRY(dev_alloc(p, &p->conv_ws[i], ws.size() * sizeof(uint16_t)));
       HIPCHK(hipMemcpyAsync(p->conv_ws[i], ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -505,6 +522,7 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       std::vector<uint16_t> ws;
       const float prescale = split_conv_weights(t, cfg->v_f_len, p->head_k, 1, ws);
       p->head_ws_bytes = ws.size() * sizeof(uint16_t);
+      ws.resize(ws.size() + ODEVIO_ZERO_PAGE_BYTES / sizeof(uint16_t), 0);
       TRY(dev_alloc(p, &p->head_ws, ws.size() * sizeof(uint16_t)));
       HIPCHK(hipMemcpyAsync(p->head_ws, ws.data(), ws.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -796,6 +814,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.ld_out = cs.cout; a.terms = p->conv_math == 2 ? 1 : 3;
     a.in_bytes = extent_of(p, in, (size_t)P * a.Hi * a.Wi * a.Cin * sizeof(float));
     a.w_bytes = p->conv_ws_bytes[i];
+    set_off32(p, a, in);
     a.out_bytes = extent_of(p, out, (size_t)a.M * a.Cout * sizeof(float));
     {  // 256 x 256 tiles (a third fewer staged bytes per flop) where they fill whole rounds of the chip: measured
        // conv3 1400 -> 1204 us and conv3_1 1012 -> 922 us (1280 tiles = 5.0 rounds of 256 CUs), but conv4 / conv4_1
@@ -886,6 +905,7 @@ static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* f
     }
     a.in_bytes = extent_of(p, cur, (size_t)P * p->head_k * sizeof(float));
     a.w_bytes = p->head_ws_bytes;
+    set_off32(p, a, cur);
     a.out_bytes = extent_of(p, fv, ((size_t)(P - 1) * ld_fv + a.Cout) * sizeof(float));
     HIPCHK(launch_conv_f16x2(a, st));
     rc = 0;

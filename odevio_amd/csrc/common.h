@@ -66,6 +66,11 @@ struct ConvSplitArgs {
   const void* zeros;    // ODEVIO_ZERO_PAGE_BYTES zero bytes: what the LDS-DMA reads for taps outside the image
   size_t in_bytes, w_bytes, out_bytes, partial_bytes;   // extents of in / w / out / partial: checked on the host at
                                                         // every launch, and per access by the audit build
+  // 32-bit addressing of the DMA sources (off32 = 1): both `in` and `w` are followed, inside their own allocation, by
+  // ODEVIO_ZERO_PAGE_BYTES zero bytes at byte offset in_zero_off / w_zero_off (< 2^32): a lane's source is base (scalar) +
+  // a 32-bit offset, and "outside the image" is one more offset instead of a second 64-bit pointer to select from
+  unsigned in_zero_off, w_zero_off;
+  int off32;
   const float* scale;   // [Cout] (BatchNorm scale with the weights' power-of-two pre-scale folded in)
   const float* shift;   // [Cout]
   void* out;

@@ -27,6 +27,7 @@
 // which makes the ds_read_b128 fragment reads conflict-free.  Three stages (48 KB each); taps outside the image read
 // a zero page.  Barriers are raw s_barrier with counted vmcnt (a __syncthreads() would drain the DMAs).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -56,14 +57,14 @@ template <int BN> struct HTile {
 // TERMS = 3: the fp32-grade product described above.  TERMS = 1 (ODEVIO_CONV_MATH=f16, outside the fp32 parity claim):
 // only h_w h_x, i.e. plain fp16 operands (11-bit significands) with fp32 accumulation - the reduced-precision mode of
 // BASELINE configs[2]; same layout, same kernel, a third of the MFMAs.
-template <int TERMS, int BN>
+template <int TERMS, int BN, bool O32>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_kernel(ConvSplitArgs a) {
   typedef HTile<BN> T;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // T::LDS bytes
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS destinations of the DMAs (M0) need no readfirstlane per use
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: see conv_igemm_kernel
   const int NT = gridDim.y;
@@ -89,15 +90,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const unsigned char* in_b = reinterpret_cast<const unsigned char*>(a.in);
   const unsigned char* w_b = reinterpret_cast<const unsigned char*>(a.w);
   const int lr = lane >> 3, lslot = lane & 7;
+  // Two addressing forms.  O32 (the production form whenever the buffers are the plan's own and smaller than 4 GB): a
+  // lane's source = scalar base + 32-bit offset; per pixel row a bit mask says which taps fall inside the image, and
+  // "outside" is the offset of the zero bytes that follow the activations inside the same allocation.  Per DMA that is
+  // a bit test, a select and an add on 32-bit registers - the 64-bit form below needs two range compares, two 64-bit
+  // selects and a 64-bit add, and the DMA-issue work of this kernel is what the MFMAs wait for.
   const unsigned char* a_row[4];
   int a_hi0[4], a_wi0[4];
   int a_poff[4];                            // byte offset of this lane's source piece inside the 128-byte block
+  unsigned a_off[4], a_mask[4];
+  unsigned a_zoff[2] = {0, 0};              // zero-tail offsets: the source piece of row q only depends on q & 1
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = 32 * wave + 8 * q + lr;   // row of the pixel tile
     a_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
     const int m = m0 + r;
+    a_off[q] = 0; a_mask[q] = 0;
+    if (q < 2) a_zoff[q] = a.in_zero_off + a_poff[q];   // rows 8q + lr and 8(q+2) + lr share (row >> 1) & 7
     if (m < a.M) {
       const int img = m / HoWo;
       const int rem = m - img * HoWo;
@@ -105,9 +115,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int wo = rem - ho * a.Wo;
       a_hi0[q] = ho * a.stride - a.pad;
       a_wi0[q] = wo * a.stride - a.pad;
-      // (hi0, wi0) may be negative: the pointer is only ever dereferenced with a tap offset that brings it inside the
-      // image (the `ok` test in issue_tile), never as it stands
-      a_row[q] = in_b + ((ptrdiff_t)img * a.Hi * a.Wi + (ptrdiff_t)a_hi0[q] * a.Wi + a_wi0[q]) * px_bytes + a_poff[q];
+      // (hi0, wi0) may be negative: the pointer / offset is only ever used with a tap offset that brings it inside the
+      // image (the `ok` test in issue_tile), never as it stands (the 32-bit offset wraps and un-wraps exactly)
+      const ptrdiff_t base = ((ptrdiff_t)img * a.Hi * a.Wi + (ptrdiff_t)a_hi0[q] * a.Wi + a_wi0[q]) * px_bytes + a_poff[q];
+      a_row[q] = in_b + base;
+      if (O32) {
+        a_off[q] = (unsigned)base;
+        unsigned mask = 0;
+        for (int kh = 0; kh < a.KH; ++kh)
+          for (int kw = 0; kw < a.KW; ++kw)
+            if ((unsigned)(a_hi0[q] + kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + kw) < (unsigned)a.Wi) mask |= 1u << (kh * a.KW + kw);
+        a_mask[q] = mask;
+      }
     } else {
       a_row[q] = in_b;
       a_hi0[q] = -(1 << 28);                // rows past M fail the `ok` test for every tap: zero page
@@ -116,12 +135,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const unsigned char* b_row[T::BDMA];
   int b_poff[T::BDMA];
+  unsigned b_off[T::BDMA], b_sel[T::BDMA];
 #pragma unroll
   for (int q = 0; q < T::BDMA; ++q) {
     const int r = 8 * T::BDMA * wave + 8 * q + lr;   // row of the weight tile
     b_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
     const int n = n0 + r;
     b_row[q] = (n < a.Cout) ? w_b + (size_t)n * nk * HROW + b_poff[q] : nullptr;
+    b_off[q] = (n < a.Cout) ? (unsigned)((size_t)n * nk * HROW) + b_poff[q] : a.w_zero_off + b_poff[q];
+    b_sel[q] = (n < a.Cout) ? 0xffffffffu : 0u;     // rows past Cout stay on the zero bytes whatever the K-tile
   }
   const unsigned char* zero_b = reinterpret_cast<const unsigned char*>(a.zeros);
 
@@ -133,11 +155,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // K-tile walk (workgroup-uniform): channel group MAJOR, tap MINOR (the taps of one group re-read the same pixels
   // shifted by one, back to back: L1/L2 hits), without divisions.
-  int t_kh = 0, t_kw = 0, t_g = 0, t_aoff = 0, t_boff = 0;
+  int t_kh = 0, t_kw = 0, t_g = 0, t_aoff = 0, t_boff = 0, t_tap = 0;
   {
     const int g = kt_begin / taps;
     const int tap = kt_begin - g * taps;
     t_g = g;
+    t_tap = tap;
     t_kh = tap / a.KW;
     t_kw = tap - t_kh * a.KW;
     t_aoff = (t_kh * a.Wi + t_kw) * px_bytes + g * HROW;
@@ -145,6 +168,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   auto next_tile = [&]() {
     ++t_kw;
+    ++t_tap;
     t_aoff += px_bytes;
     t_boff += HROW;
     if (t_kw == a.KW) {
@@ -153,6 +177,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       t_aoff += (a.Wi - a.KW) * px_bytes;
       if (t_kh == a.KH) {
         t_kh = 0;
+        t_tap = 0;
         ++t_g;
         t_aoff = t_g * HROW;
       }
@@ -161,6 +186,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // T::DMAS DMAs per wave and tile; the LDS destination is wave-uniform (+ lane * 16 by the hardware)
   auto issue_tile = [&](int stage) __attribute__((always_inline)) {
     unsigned char* dst = lds + stage * T::STAGE;
+    if (O32) {
+      const unsigned bit = 1u << t_tap;
+      const unsigned char* zin = in_b + a.in_zero_off;      // audit only
+      const unsigned char* zw = w_b + a.w_zero_off;
+      (void)zin; (void)zw;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned off = (a_mask[q] & bit) ? a_off[q] + (unsigned)t_aoff : a_zoff[q & 1];
+        const unsigned char* pa = in_b + off;
+        pa = AUDIT_SRC(pa, 16, in_b, a.in_bytes, zin, a.status, AK_CONV_A);
+        __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + (32 * wave + 8 * q) * HROW), 16, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < T::BDMA; ++q) {
+        // (the wide tile needs Cout % 256 == 0: no weight row past Cout, no mask)
+        const unsigned off = BN == 256 ? b_off[q] + (unsigned)t_boff : b_off[q] + ((unsigned)t_boff & b_sel[q]);
+        const unsigned char* pb = w_b + off;
+        pb = AUDIT_SRC(pb, 16, w_b, a.w_bytes, zw, a.status, AK_CONV_B);
+        __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + HA_BYTES + (8 * T::BDMA * wave + 8 * q) * HROW), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool ok = (unsigned)(a_hi0[q] + t_kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + t_kw) < (unsigned)a.Wi;
@@ -241,34 +288,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (T::LOOKAHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::DMAS) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  int st_cur = 0, st_nxt = T::LOOKAHEAD;   // stage holding tile j / stage to refill with tile j+LOOKAHEAD
-#if defined(ODEVIO_EXP_NODMA)
-  // timing experiment (results are wrong): the K loop without staging - fragment reads + MFMAs on whatever the prologue staged
-  for (int j = 0; j < ntile; ++j) multiply(T::LOOKAHEAD == 2 ? (j & 1) : 0);   // only stages the prologue filled
-#elif defined(ODEVIO_EXP_NOMFMA)
-  // timing experiment (results are wrong): staging, waits and barriers only
-  for (int j = 0; j < ntile; ++j) {
+  // One K-tile: request tile j+LOOKAHEAD into the stage tile j-1 was read from (everyone is past that barrier), multiply
+  // tile j, wait until tile j+1 has landed, barrier.  The stage indices are COMPILE-TIME constants (the loop is unrolled
+  // over the ring): every LDS address is then lane constant + immediate and every DMA destination an immediate M0 - the
+  // per-K-tile address arithmetic this kernel can do without (section 5.7: the issue work of the staging is what the
+  // MFMAs wait for).
+  auto step = [&](int j, auto cur, auto nxt) __attribute__((always_inline)) {
     if (j + T::LOOKAHEAD < ntile) next_tile();
-    issue_tile(st_nxt);
+    issue_tile(decltype(nxt)::value);
+    multiply(decltype(cur)::value);
     if (T::LOOKAHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::DMAS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    st_nxt = st_cur;
-    st_cur = st_cur + 1 == T::NSTAGE ? 0 : st_cur + 1;
+  };
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  typedef std::integral_constant<int, 2> S2;
+  if constexpr (T::NSTAGE == 3) {
+    for (int j = 0;;) {
+      if (j >= ntile) break;
+      step(j++, S0{}, S2{});
+      if (j >= ntile) break;
+      step(j++, S1{}, S0{});
+      if (j >= ntile) break;
+      step(j++, S2{}, S1{});
+    }
+  } else {
+    // the wide tile keeps 128 accumulator registers per lane: unrolled over its two stages the compiler's look-ahead
+    // spills (352 bytes of scratch per lane in the loop), so its stage index stays a run-time value
+    for (int j = 0; j < ntile; ++j) {
+      if (j + T::LOOKAHEAD < ntile) next_tile();
+      issue_tile((j + 1) & 1);
+      multiply(j & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
-  multiply(0);
-#else
-  for (int j = 0; j < ntile; ++j) {
-    if (j + T::LOOKAHEAD < ntile) next_tile();
-    issue_tile(st_nxt);                    // -> the stage tile j-1 was read from (everyone is past that barrier)
-    multiply(st_cur);
-    if (T::LOOKAHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::DMAS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    st_nxt = st_cur;
-    st_cur = st_cur + 1 == T::NSTAGE ? 0 : st_cur + 1;
-  }
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS
 
   // ---- epilogue.  C/D map of the 16x16 MFMA: column (= pixel) = lane&15, row (= channel) = 4*(lane>>4) + r
@@ -306,9 +361,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
-#if defined(ODEVIO_EXP_NODMA) || defined(ODEVIO_EXP_NOMFMA)
-  range_bad = false;   // timing experiments compute garbage by design
-#endif
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 }
 
@@ -333,22 +385,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16x2_kernel(ConvSplitArgs 
     if (a.out_split) range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), m, n, a.Cout, v);
     else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + m * (size_t)a.ld_out + n) = v;
   }
-#if defined(ODEVIO_EXP_NODMA) || defined(ODEVIO_EXP_NOMFMA)
-  range_bad = false;
-#endif
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 }
 
-template <int TERMS, int BN>
-static hipError_t launch_tile(const ConvSplitArgs& a, dim3 grid, hipStream_t st) {
+template <int TERMS, int BN, bool O32>
+static hipError_t launch_tile_o(const ConvSplitArgs& a, dim3 grid, hipStream_t st) {
   static unsigned long long attr_mask = 0;   // the dynamic-LDS attribute is per device
   if (first_use_on_device(attr_mask)) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<TERMS, BN>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<TERMS, BN, O32>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, HTile<BN>::LDS);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((conv_f16x2_kernel<TERMS, BN>), grid, dim3(512), HTile<BN>::LDS, st, a);
+  hipLaunchKernelGGL((conv_f16x2_kernel<TERMS, BN, O32>), grid, dim3(512), HTile<BN>::LDS, st, a);
   return hipSuccess;
+}
+template <int TERMS, int BN>
+static hipError_t launch_tile(const ConvSplitArgs& a, dim3 grid, hipStream_t st) {
+  return a.off32 ? launch_tile_o<TERMS, BN, true>(a, grid, st) : launch_tile_o<TERMS, BN, false>(a, grid, st);
 }
 
 // Host-side check of what the kernel and its grid assume, at every launch (cheap; the kernel's DMAs are not
@@ -367,6 +420,11 @@ static bool conv_args_consistent(const ConvSplitArgs& a) {
   }
   const size_t out_need = a.out_split ? (size_t)a.M * a.Cout * 4 : ((size_t)(a.M - 1) * a.ld_out + a.Cout) * 4;
   if (a.out_bytes < out_need || (!a.out_split && a.ld_out < a.Cout)) return false;
+  if (a.off32) {   // the zero bytes behind `in` and `w` must be addressable with 32 bits and lie behind the data
+    if (a.KH * a.KW > 32) return false;
+    if ((size_t)a.in_zero_off < (size_t)a.N * a.Hi * a.Wi * a.Cin * 4 || (size_t)a.in_zero_off + ODEVIO_ZERO_PAGE_BYTES > 0xffffffffull) return false;
+    if ((size_t)a.w_zero_off < (size_t)a.Cout * nk * HROW || (size_t)a.w_zero_off + ODEVIO_ZERO_PAGE_BYTES > 0xffffffffull) return false;
+  }
   return a.in && a.w && a.zeros && a.out && a.scale && a.shift && a.status;
 }
 

@@ -18,13 +18,13 @@ GTOL = 1e-3
 
 def _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names, dtype=torch.float64):
     leaves = {k: v.clone().to(dtype).requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
-    fv64, fi64 = fv.to(dtype).requires_grad_(True), fi.to(dtype).requires_grad_(True)
-    hc64 = None if hc is None else hc.to(dtype).requires_grad_(True)
+    fv64, fi64 = fv.clone().to(dtype).requires_grad_(True), fi.clone().to(dtype).requires_grad_(True)   # clones: .to() of the same dtype is the tensor itself
+    hc64 = None if hc is None else hc.clone().to(dtype).requires_grad_(True)
     with_ode = opt.model_type == "ode-rnn"
     # the step sizes an adaptive controller picked are constants of the differentiation (the backward replays the accepted steps)
     poses, h_T = oc.pose_ode_rnn(leaves, fv64, fi64, ts, hc64, opt, dtype=dtype, with_ode=with_ode, detach_controller=True)
-    loss = 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3].double()) + \
-        torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:].double())
+    loss = 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3].to(dtype)) + \
+        torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:].to(dtype))
     loss.backward()
     out = {"fv": fv64.grad, "fi": fi64.grad, "loss": loss.detach(), "poses": poses.detach()}
     if hc64 is not None:
