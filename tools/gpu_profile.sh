@@ -28,5 +28,9 @@ done
 db=$(find $OUT/trace -name '*_results.db' | head -n 1)
 python3 $ROOT/tools/kernel_trace_summary.py "$db" $OUT/kernel_stats.csv > $OUT/kernel_stats.txt 2>&1
 python3 $ROOT/tools/pmc_summary.py $OUT $NFWD > $OUT/pmc_traffic.json 2> $OUT/pmc_summary.err
+# derived utilisation figures (clock, MFMA busy, LDS, TA, wave wait) per kernel named in $DERIVE, from the extra passes
+for k in ${DERIVE:-}; do
+  python3 $ROOT/tools/pmc_derive.py $OUT/pmc $k 100 > $OUT/pmc_${k}_derived.json 2>> $OUT/pmc_summary.err
+done
 cat $OUT/kernel_stats.txt | head -n 14
 exit 0
