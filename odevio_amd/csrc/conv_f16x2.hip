@@ -79,6 +79,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (mt_idx * HBM_ >= a.M) return;
   const int m0 = mt_idx * HBM_;
   const int n0 = nt_idx * BN;
+#ifdef ODEVIO_STAMPS   // diagnostic build (make STAMPS=1): phase stamps of workgroup 0 into the words behind the status (odevio_debug_stamps)
+  const bool stamper = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.status + 8);
+  if (stamper) stamps[0] = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- loader role.  One DMA instruction = 8 rows x 8 pieces of 16 B; lane l brings LDS slot (l & 7) of row
   // (l >> 3), which holds source piece slot ^ ((row >> 1) & 7).  Wave w stages pixel rows 32w .. 32w+31 (4 DMAs) and
@@ -293,6 +298,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // over the ring): every LDS address is then lane constant + immediate and every DMA destination an immediate M0 - the
   // per-K-tile address arithmetic this kernel can do without (section 5.7: the issue work of the staging is what the
   // MFMAs wait for).
+#ifdef ODEVIO_STAMPS
+  if (stamper) stamps[1] = __builtin_amdgcn_s_memtime();   // prologue done: first tile landed
+#endif
   auto step = [&](int j, auto cur, auto nxt) __attribute__((always_inline)) {
     if (j + T::LOOKAHEAD < ntile) next_tile();
     issue_tile(decltype(nxt)::value);
@@ -325,6 +333,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS
+#ifdef ODEVIO_STAMPS
+  if (stamper) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[4] = (unsigned long long)ntile; }
+#endif
 
   // ---- epilogue.  C/D map of the 16x16 MFMA: column (= pixel) = lane&15, row (= channel) = 4*(lane>>4) + r
   bool range_bad = false;
@@ -362,6 +373,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
+#ifdef ODEVIO_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stamper) stamps[3] = __builtin_amdgcn_s_memtime();   // epilogue stores retired
+#endif
 }
 
 // Deterministic split-K combine: sums the slabs in slab order, then the same epilogue; 4 channels per thread.
