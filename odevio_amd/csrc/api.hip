@@ -815,6 +815,10 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.in_bytes = extent_of(p, in, (size_t)P * a.Hi * a.Wi * a.Cin * sizeof(float));
     a.w_bytes = p->conv_ws_bytes[i];
     set_off32(p, a, in);
+    {
+      static const char* sl = getenv("ODEVIO_STAMP_LAYER");   // diagnostic build: which layer's launch writes the phase stamps
+      a.stamp = sl ? atoi(sl) == i : 1;
+    }
     a.out_bytes = extent_of(p, out, (size_t)a.M * a.Cout * sizeof(float));
     {  // 256 x 256 tiles (a third fewer staged bytes per flop) where they fill whole rounds of the chip: measured
        // conv3 1400 -> 1204 us and conv3_1 1012 -> 922 us (1280 tiles = 5.0 rounds of 256 CUs), but conv4 / conv4_1

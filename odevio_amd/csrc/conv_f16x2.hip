@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int m0 = mt_idx * HBM_;
   const int n0 = nt_idx * BN;
 #ifdef ODEVIO_STAMPS   // diagnostic build (make STAMPS=1): phase stamps of workgroup 0 into the words behind the status (odevio_debug_stamps)
-  const bool stamper = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  const bool stamper = a.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.status + 8);
   if (stamper) stamps[0] = __builtin_amdgcn_s_memtime();
 #endif
@@ -332,41 +332,98 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_s_barrier();
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unused look-ahead DMAs must not outlive the workgroup's LDS ...
+  __builtin_amdgcn_s_barrier();                      // ... nor land in it after another wave has begun staging its epilogue there
 #ifdef ODEVIO_STAMPS
   if (stamper) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[4] = (unsigned long long)ntile; }
 #endif
 
   // ---- epilogue.  C/D map of the 16x16 MFMA: column (= pixel) = lane&15, row (= channel) = 4*(lane>>4) + r
   bool range_bad = false;
+  if (a.out_split && a.splitk <= 1) {
+    // P2 output through LDS (free now: every wave is past the last K-tile's barrier).  Stored straight from the
+    // accumulators a wave instruction writes 8 bytes to each of 64 places in 16 different cache lines - partial lines, and
+    // the phase stamps showed the store ISSUE of that epilogue taking 13 - 26 k cycles per tile (11 - 22 % of a
+    // workgroup's life).  The tile's output is contiguous in memory per pixel (BN channels x 4 bytes = the [group][piece][32]
+    // blocks of that pixel), so the split values are laid out in LDS in MEMORY order (pixel stride + 16 bytes against
+    // bank conflicts) and leave as 16 bytes per lane, 1 KB contiguous per wave instruction, whole lines only.
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int PXB = BN * 4;                       // bytes of one pixel's slice of this tile
+    constexpr int PXS = PXB + 16;                     // its stride in LDS
+    constexpr int PASS_PX = BN == 128 ? HBM_ : 64;    // pixels staged per pass (wide tile: one wave row at a time)
+    constexpr int NPASS = HBM_ / PASS_PX;
+    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
+    const int gpp = a.Cout >> 5;                      // 128-byte blocks per pixel in memory
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fi;
-    if (m >= a.M) continue;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      if (BN == 128 || wm == pass) {
 #pragma unroll
-    for (int nb4 = 0; nb4 < NB; ++nb4) {
-      const int n = n0 + wn * (BN / 2) + nb4 * 16 + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
-      if (n >= a.Cout) continue;
-      f32x4 v = acc[i][nb4];
-      if (a.splitk > 1) {
-        float* dst = a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n;
-        if (AUDIT_DST_OK(dst, 16, a.partial, a.partial_bytes, a.status, AK_CONV_SLAB)) *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+        for (int i = 0; i < 4; ++i) {
+          const int pl = (BN == 128 ? wm * 64 : 0) + i * 16 + fi;          // pixel inside the pass
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = v[e] * sc[e] + sh[e];
-          v[e] = x > 0.f ? x : x * a.slope;
+          for (int nb4 = 0; nb4 < NB; ++nb4) {
+            const int nl = wn * (BN / 2) + nb4 * 16 + 4 * fh;              // channel inside the tile
+            const int n = min(n0 + nl, a.Cout - 4);                        // (channels past Cout are never stored)
+            f32x4 v = acc[i][nb4];
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = v[e] * sc[e] + sh[e];
+              x = x > 0.f ? x : x * a.slope;
+              range_bad |= !(fabsf(x) <= 65504.f) && (n0 + nl < a.Cout) && (m0 + (BN == 128 ? 0 : pass * PASS_PX) + pl < a.M);
+              h[e] = (_Float16)x;
+              l[e] = (_Float16)(x - (float)h[e]);
+            }
+            unsigned char* q = lds + pl * PXS + (nl >> 5) * 128 + (nl & 31) * 2;
+            *reinterpret_cast<f16x4*>(q) = h;
+            *reinterpret_cast<f16x4*>(q + 64) = l;
+          }
         }
-        if (a.out_split) {
-#ifdef ODEVIO_AUDIT
-          const unsigned char* q0 = reinterpret_cast<unsigned char*>(a.out) + ((size_t)m * (a.Cout >> 5) + (n >> 5)) * 128 + (n & 31) * 2;
-          if (!AUDIT_DST_OK(q0, 72, a.out, a.out_bytes, a.status, AK_CONV_OUT)) continue;
-#endif
-          range_bad |= store_pair4(reinterpret_cast<unsigned char*>(a.out), (size_t)m, n, a.Cout, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      constexpr int SWEEPS = PASS_PX * PXB / (512 * 16);
+#pragma unroll
+      for (int it = 0; it < SWEEPS; ++it) {
+        const int o = (it * 512 + tid) * 16;          // byte offset inside the pass, memory order
+        const int pl = o / PXB, within = o - pl * PXB;
+        const int m = m0 + pass * PASS_PX + pl;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(lds + pl * PXS + within);
+        if (m < a.M && (n0 >> 5) + (within >> 7) < gpp) {
+          unsigned char* dst = outb + ((size_t)m * gpp + (n0 >> 5)) * 128 + within;
+          if (AUDIT_DST_OK(dst, 16, a.out, a.out_bytes, a.status, AK_CONV_OUT)) *reinterpret_cast<u32x4*>(dst) = v;
+        }
+      }
+      if (pass + 1 < NPASS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // the next pass overwrites the staging area
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fi;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int nb4 = 0; nb4 < NB; ++nb4) {
+        const int n = n0 + wn * (BN / 2) + nb4 * 16 + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
+        if (n >= a.Cout) continue;
+        f32x4 v = acc[i][nb4];
+        if (a.splitk > 1) {
+          float* dst = a.partial + ((size_t)blockIdx.z * a.M + m) * a.Cout + n;
+          if (AUDIT_DST_OK(dst, 16, a.partial, a.partial_bytes, a.status, AK_CONV_SLAB)) *reinterpret_cast<f32x4*>(dst) = v;
         } else {
-          float* dst = reinterpret_cast<float*>(a.out) + (size_t)m * a.ld_out + n;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = v[e] * sc[e] + sh[e];
+            v[e] = x > 0.f ? x : x * a.slope;
+          }
+          float* dst = reinterpret_cast<float*>(a.out) + (size_t)m * a.ld_out + n;   // fp32 output (conv6 -> head in f32 mode, block API)
           if (AUDIT_DST_OK(dst, 16, a.out, a.out_bytes, a.status, AK_CONV_OUT)) *reinterpret_cast<f32x4*>(dst) = v;
         }
       }
