@@ -51,7 +51,8 @@ template <int BN> struct HTile {
   static constexpr int LOOKAHEAD = NSTAGE - 1;            // tiles of DMA in flight beyond the one being multiplied
   static constexpr int BDMA = BN / 64;                    // weight-row DMAs per wave and K-tile (8 rows each)
   static constexpr int DMAS = 4 + BDMA;                   // DMAs per wave and K-tile
-  static constexpr int LDS = NSTAGE * STAGE;              // 144 KB / 128 KB
+  // 144 KB / 130 KB: the stages, or (wide tile) the epilogue's staging area of 128 pixels x (1024 + 16) bytes if larger
+  static constexpr int LDS = NSTAGE * STAGE > 128 * (BN * 4 + 16) || BN == 128 ? NSTAGE * STAGE : 128 * (BN * 4 + 16);
 };
 
 // TERMS = 3: the fp32-grade product described above.  TERMS = 1 (ODEVIO_CONV_MATH=f16, outside the fp32 parity claim):
@@ -351,16 +352,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int PXB = BN * 4;                       // bytes of one pixel's slice of this tile
     constexpr int PXS = PXB + 16;                     // its stride in LDS
-    constexpr int PASS_PX = BN == 128 ? HBM_ : 64;    // pixels staged per pass (wide tile: one wave row at a time)
+    // BN = 128: the whole tile in one pass.  Wide tile (256 KB of output, 130 KB of LDS): two passes, and in each EVERY wave
+    // stages half of its own pixel rows (i = 2 pass, 2 pass + 1), so that all eight waves convert and write in both passes
+    constexpr int PASS_PX = BN == 128 ? HBM_ : 128;
     constexpr int NPASS = HBM_ / PASS_PX;
+    constexpr int IPP = 4 / NPASS;                    // 16-pixel blocks of a wave per pass
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int gpp = a.Cout >> 5;                      // 128-byte blocks per pixel in memory
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-      if (BN == 128 || wm == pass) {
+      {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int pl = (BN == 128 ? wm * 64 : 0) + i * 16 + fi;          // pixel inside the pass
+        for (int ii = 0; ii < IPP; ++ii) {
+          const int i = pass * IPP + ii;
+          const int pl = wm * (16 * IPP) + ii * 16 + fi;                    // pixel inside the pass
 #pragma unroll
           for (int nb4 = 0; nb4 < NB; ++nb4) {
             const int nl = wn * (BN / 2) + nb4 * 16 + 4 * fh;              // channel inside the tile
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; ++e) {
               float x = v[e] * sc[e] + sh[e];
               x = x > 0.f ? x : x * a.slope;
-              range_bad |= !(fabsf(x) <= 65504.f) && (n0 + nl < a.Cout) && (m0 + (BN == 128 ? 0 : pass * PASS_PX) + pl < a.M);
+              range_bad |= !(fabsf(x) <= 65504.f) && (n0 + nl < a.Cout) && (m0 + wm * 64 + i * 16 + fi < a.M);
               h[e] = (_Float16)x;
               l[e] = (_Float16)(x - (float)h[e]);
             }
@@ -390,7 +395,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int it = 0; it < SWEEPS; ++it) {
         const int o = (it * 512 + tid) * 16;          // byte offset inside the pass, memory order
         const int pl = o / PXB, within = o - pl * PXB;
-        const int m = m0 + pass * PASS_PX + pl;
+        // pixel of the tile behind staged pixel pl: wave row pl / (16 IPP), its blocks pass * IPP ..
+        const int m = m0 + (pl / (16 * IPP)) * 64 + pass * (16 * IPP) + (pl & (16 * IPP - 1));
         const u32x4 v = *reinterpret_cast<const u32x4*>(lds + pl * PXS + within);
         if (m < a.M && (n0 >> 5) + (within >> 7) < gpp) {
           unsigned char* dst = outb + ((size_t)m * gpp + (n0 >> 5)) * 128 + within;
