@@ -402,6 +402,7 @@ __global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
   unsigned target = 0;
   bool healthy = true;
   bool range_bad = false;
+  unsigned absmax = 0;   // largest |x| bit pattern this lane stored (NaN / infinity compare above every finite value)
   // (A deliberate half-tile phase offset between the groups was measured 4 % slower than letting them drift.)
 
   for (int tile = blockIdx.x * 2 + grp; tile < a.n_tiles && healthy; tile += gridDim.x * 2) {
@@ -480,14 +481,15 @@ __global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
             const int n = nt * 32 + 8 * g + 4 * fh;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(sc_s + n);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(sc_s + 64 + n);
-            f16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float x = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
-              x = fmaxf(x, x * a.slope);
-              range_bad |= !(fabsf(x) <= 65504.f);
-              h[e] = (_Float16)x;
-              l[e] = (_Float16)(x - (float)h[e]);
+            // vector BatchNorm + LeakyReLU (max(x, slope x), 0 < slope < 1), packed conversions, integer-maximum range check
+            f32x4 x = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+            x = x * sc + sh;
+            x = __builtin_elementwise_max(x, x * a.slope);
+            const f16x4 h = __builtin_convertvector(x, f16x4);
+            const f16x4 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), f16x4);
+            {
+              const u32x4 xb = __builtin_bit_cast(u32x4, x) & 0x7fffffffu;
+              absmax = max(absmax, max(max(xb[0], xb[1]), max(xb[2], xb[3])));
             }
             unsigned char* q = stg + fi * 264 + nt * 128 + (8 * g + 4 * fh) * 2;
             *reinterpret_cast<f16x4*>(q) = h;
@@ -517,6 +519,7 @@ __global__ __launch_bounds__(512) void conv1_f16x2_g2_kernel(Conv1Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     healthy = healthy && group_barrier(ctr, target, lane);
   }
+  range_bad |= absmax > 0x477fe000u;   // bits of 65504.0f
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
   if (!healthy) a.status[ODEVIO_STATUS_RANGE + 1] = 1;
 }

@@ -359,6 +359,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int IPP = 4 / NPASS;                    // 16-pixel blocks of a wave per pass
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int gpp = a.Cout >> 5;                      // 128-byte blocks per pixel in memory
+    unsigned absmax = 0;                              // largest |x| bit pattern this lane produced
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       {
@@ -370,17 +371,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int nb4 = 0; nb4 < NB; ++nb4) {
             const int nl = wn * (BN / 2) + nb4 * 16 + 4 * fh;              // channel inside the tile
             const int n = min(n0 + nl, a.Cout - 4);                        // (channels past Cout are never stored)
-            f32x4 v = acc[i][nb4];
             const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
-            f16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float x = v[e] * sc[e] + sh[e];
-              x = x > 0.f ? x : x * a.slope;
-              range_bad |= !(fabsf(x) <= 65504.f) && (n0 + nl < a.Cout) && (m0 + wm * 64 + i * 16 + fi < a.M);
-              h[e] = (_Float16)x;
-              l[e] = (_Float16)(x - (float)h[e]);
+            // BatchNorm + LeakyReLU on vectors (packed fma / mul / max; slope in [0, 1]: leaky(x) = max(x, slope x)), the
+            // two pieces by vector conversions (packed cvt); the range check is ONE integer maximum over |x| bit patterns
+            // (NaN and infinity compare above every finite number), tested once per lane at the end
+            f32x4 x = acc[i][nb4] * sc + sh;
+            x = __builtin_elementwise_max(x, x * a.slope);
+            const f16x4 h = __builtin_convertvector(x, f16x4);
+            const f16x4 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), f16x4);
+            if ((n0 + nl < a.Cout) && (m0 + wm * 64 + i * 16 + fi < a.M)) {
+              const u32x4 xb = __builtin_bit_cast(u32x4, x) & 0x7fffffffu;
+              absmax = max(absmax, max(max(xb[0], xb[1]), max(xb[2], xb[3])));
             }
             unsigned char* q = lds + pl * PXS + (nl >> 5) * 128 + (nl & 31) * 2;
             *reinterpret_cast<f16x4*>(q) = h;
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_barrier();                 // the next pass overwrites the staging area
       }
     }
+    range_bad = absmax > 0x477fe000u;                 // bits of 65504.0f: anything above (incl. inf / NaN) cannot be carried as fp16 pieces
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
