@@ -817,7 +817,8 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     set_off32(p, a, in);
     {
       static const char* sl = getenv("ODEVIO_STAMP_LAYER");   // diagnostic build: which layer's launch writes the phase stamps
-      a.stamp = sl ? atoi(sl) == i : 1;
+      static const char* sw = getenv("ODEVIO_STAMP_WG");      // ... and which workgroup (linear index; default 0: a first-round one)
+      a.stamp = (sl ? atoi(sl) == i : 1) ? 1 + (sw ? atoi(sw) : 0) : 0;
     }
     a.out_bytes = extent_of(p, out, (size_t)a.M * a.Cout * sizeof(float));
     {  // 256 x 256 tiles (a third fewer staged bytes per flop) where they fill whole rounds of the chip: measured

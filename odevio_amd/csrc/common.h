@@ -71,7 +71,7 @@ struct ConvSplitArgs {
   // a 32-bit offset, and "outside the image" is one more offset instead of a second 64-bit pointer to select from
   unsigned in_zero_off, w_zero_off;
   int off32;
-  int stamp;            // diagnostic build (STAMPS=1): this launch writes workgroup 0's phase stamps
+  int stamp;            // diagnostic build (STAMPS=1): 0, or 1 + the linear index of the workgroup whose phase stamps this launch writes
   const float* scale;   // [Cout] (BatchNorm scale with the weights' power-of-two pre-scale folded in)
   const float* shift;   // [Cout]
   void* out;

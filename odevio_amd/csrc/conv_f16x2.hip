@@ -81,9 +81,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int m0 = mt_idx * HBM_;
   const int n0 = nt_idx * BN;
 #ifdef ODEVIO_STAMPS   // diagnostic build (make STAMPS=1): phase stamps of workgroup 0 into the words behind the status (odevio_debug_stamps)
-  const bool stamper = a.stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  const bool stamper = a.stamp && (int)(blockIdx.y * gridDim.x + blockIdx.x) == a.stamp - 1 && blockIdx.z == 0 && tid == 0;
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.status + 8);
-  if (stamper) stamps[0] = __builtin_amdgcn_s_memtime();
+  if (stamper) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[5] = __builtin_amdgcn_s_memrealtime(); }   // [5], [6]: the 100 MHz clock, for the shader clock held
 #endif
 
   // ---- loader role.  One DMA instruction = 8 rows x 8 pieces of 16 B; lane l brings LDS slot (l & 7) of row
@@ -107,6 +107,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned a_off[4], a_mask[4];
   unsigned a_zoff[2] = {0, 0};              // zero-tail offsets: the source piece of row q only depends on q & 1
   const int HoWo = a.Ho * a.Wo;
+  // (image, row, column) of this lane's first pixel row by division; its other three rows are 8, 16, 24 pixels further
+  // on and follow by carries (this set-up is on every tile's critical path: nothing is in flight until it is done)
+  int p_img, p_ho, p_wo;
+  {
+    const int m = m0 + 32 * wave + lr;
+    p_img = m / HoWo;
+    const int rem = m - p_img * HoWo;
+    p_ho = rem / a.Wo;
+    p_wo = rem - p_ho * a.Wo;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = 32 * wave + 8 * q + lr;   // row of the pixel tile
@@ -115,10 +125,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     a_off[q] = 0; a_mask[q] = 0;
     if (q < 2) a_zoff[q] = a.in_zero_off + a_poff[q];   // rows 8q + lr and 8(q+2) + lr share (row >> 1) & 7
     if (m < a.M) {
-      const int img = m / HoWo;
-      const int rem = m - img * HoWo;
-      const int ho = rem / a.Wo;
-      const int wo = rem - ho * a.Wo;
+      const int img = p_img, ho = p_ho, wo = p_wo;
       a_hi0[q] = ho * a.stride - a.pad;
       a_wi0[q] = wo * a.stride - a.pad;
       // (hi0, wi0) may be negative: the pointer / offset is only ever used with a tap offset that brings it inside the
@@ -127,16 +134,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       a_row[q] = in_b + base;
       if (O32) {
         a_off[q] = (unsigned)base;
+        // taps inside the image: columns kw_lo .. kw_hi - 1 of every kernel row kh whose input row exists
+        const int kw_lo = max(0, -a_wi0[q]), kw_hi = min(a.KW, a.Wi - a_wi0[q]);
+        const unsigned kwmask = kw_hi > kw_lo ? (1u << kw_hi) - (1u << kw_lo) : 0u;
         unsigned mask = 0;
         for (int kh = 0; kh < a.KH; ++kh)
-          for (int kw = 0; kw < a.KW; ++kw)
-            if ((unsigned)(a_hi0[q] + kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + kw) < (unsigned)a.Wi) mask |= 1u << (kh * a.KW + kw);
+          if ((unsigned)(a_hi0[q] + kh) < (unsigned)a.Hi) mask |= kwmask << (kh * a.KW);
         a_mask[q] = mask;
       }
     } else {
       a_row[q] = in_b;
       a_hi0[q] = -(1 << 28);                // rows past M fail the `ok` test for every tap: zero page
       a_wi0[q] = -(1 << 28);
+    }
+    p_wo += 8;
+    while (p_wo >= a.Wo) {
+      p_wo -= a.Wo;
+      if (++p_ho == a.Ho) { p_ho = 0; ++p_img; }
     }
   }
   const unsigned char* b_row[T::BDMA];
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 #ifdef ODEVIO_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (stamper) stamps[3] = __builtin_amdgcn_s_memtime();   // epilogue stores retired
+  if (stamper) { stamps[3] = __builtin_amdgcn_s_memtime(); stamps[6] = __builtin_amdgcn_s_memrealtime(); }   // epilogue stores retired
 #endif
 }
 
@@ -502,7 +516,7 @@ static bool conv_args_consistent(const ConvSplitArgs& a) {
   const size_t out_need = a.out_split ? (size_t)a.M * a.Cout * 4 : ((size_t)(a.M - 1) * a.ld_out + a.Cout) * 4;
   if (a.out_bytes < out_need || (!a.out_split && a.ld_out < a.Cout)) return false;
   if (a.off32) {   // the zero bytes behind `in` and `w` must be addressable with 32 bits and lie behind the data
-    if (a.KH * a.KW > 32) return false;
+    if (a.KH * a.KW > 32 || a.KW > 16) return false;   // tap masks are 32-bit words built from (1 << kw) row masks
     if ((size_t)a.in_zero_off < (size_t)a.N * a.Hi * a.Wi * a.Cin * 4 || (size_t)a.in_zero_off + ODEVIO_ZERO_PAGE_BYTES > 0xffffffffull) return false;
     if ((size_t)a.w_zero_off < (size_t)a.Cout * nk * HROW || (size_t)a.w_zero_off + ODEVIO_ZERO_PAGE_BYTES > 0xffffffffull) return false;
   }
