@@ -6,7 +6,7 @@ Usage: python tools/conv_stamps.py   (spawns itself once per layer)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["ODEVIO_LIB"] = os.path.join(ROOT, "odevio_amd", "libodevio_stamps.so")
+os.environ["ODEVIO_LIB"] = os.environ.get("ODEVIO_STAMPS_LIB", os.path.join(ROOT, "odevio_amd", "libodevio_stamps.so"))
 import torch
 from odevio_amd import DeepVIO, default_opt, weights, _lib
 
