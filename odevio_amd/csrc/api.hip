@@ -769,6 +769,111 @@ static int pick_splitk_h(int M, int N, int nk) {
   return best;
 }
 
+// ---- tile plan of one fp16x2 layer.  The kernel has four tile shapes (256 or 192 pixels x 128 or 256 channels); a layer
+// is run as ONE shape (optionally split-K), or as R full rounds of the chip in one shape followed by the remaining pixels in
+// another, so that no round is left half empty: e.g. conv4 at the bench batch (81,920 pixels x 512 channels) = 2 rounds of
+// 256 x 256 tiles + exactly 1 round of 256 x 128 tiles, where 256 x 128 alone needs 5 rounds of twice the staged bytes per
+// flop and 256 x 256 alone 2.5 (= 3) rounds.  Costs are the measured K-tile and per-tile times of each shape (DESIGN.md
+// section 5.7, tools/conv_stamps.py); the plan only has to rank alternatives.
+struct ConvPhase { int wide, bm, m_begin, m_end, splitk; };
+struct ConvPlanF { int n; ConvPhase ph[2]; double cost; };
+struct ConvShape { int bm, wide; double kt_us, tile_us; };
+static const ConvShape kShapes[4] = {{256, 0, 1.10, 9.0}, {256, 1, 1.85, 15.0}, {192, 0, 0.86, 7.5}, {192, 1, 1.45, 12.0}};
+
+static double single_cost(const ConvShape& sh, long M, int N, int nk, int s, int n_cu) {
+  const int bn = sh.wide ? 256 : 128;
+  const long tiles = ((M + sh.bm - 1) / sh.bm) * ((N + bn - 1) / bn) * s;
+  const double rounds = std::ceil((double)tiles / n_cu);
+  double cost = rounds * (std::ceil((double)nk / s) * sh.kt_us + sh.tile_us);
+  if (s > 1) cost += (s + 1.0) * M * N * 4.0 / 4.0e6 + 8.0;   // slabs written and read at ~4 TB/s, one more launch
+  return cost;
+}
+
+static bool parse_shape(const char* t, ConvShape& out) {
+  for (const ConvShape& sh : kShapes) {
+    char name[8];
+    snprintf(name, sizeof name, "%s%s", sh.wide ? "w" : "n", sh.bm == 192 ? "192" : "");
+    if (!strcmp(t, name)) { out = sh; return true; }
+  }
+  return false;
+}
+
+static ConvPlanF plan_f16x2(int layer, int M, int N, int nk, int n_cu, bool off32) {
+  ConvPlanF best{};
+  best.cost = 1e30;
+  auto allowed = [&](const ConvShape& sh) { return (!sh.wide || N % 256 == 0) && (sh.bm == 256 || off32); };
+  // diagnostic override: ODEVIO_CONV_FORCE="4:w:2:n,5:w192,6:w192:s2" = layer:shape[:rounds:shape2][:sK]
+  if (const char* env = getenv("ODEVIO_CONV_FORCE")) {
+    std::string all(env);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos);
+      if (end == std::string::npos) end = all.size();
+      std::vector<std::string> tok;
+      std::string item = all.substr(pos, end - pos);
+      pos = end + 1;
+      size_t q = 0;
+      while (q <= item.size()) {
+        size_t e = item.find(':', q);
+        if (e == std::string::npos) e = item.size();
+        tok.push_back(item.substr(q, e - q));
+        q = e + 1;
+      }
+      ConvShape A, B;
+      if (tok.size() < 2 || atoi(tok[0].c_str()) != layer || !parse_shape(tok[1].c_str(), A) || !allowed(A)) continue;
+      ConvPlanF f{};
+      f.n = 1;
+      f.ph[0] = {A.wide, A.bm, 0, M, 1};
+      if (tok.size() >= 4 && parse_shape(tok[3].c_str(), B) && allowed(B)) {
+        const int ntA = N / (A.wide ? 256 : 128);
+        const long m1 = (long)atoi(tok[2].c_str()) * n_cu / ntA * A.bm;
+        if (m1 > 0 && m1 < M) {
+          f.n = 2;
+          f.ph[0].m_end = (int)m1;
+          f.ph[1] = {B.wide, B.bm, (int)m1, M, 1};
+        }
+      } else if (tok.size() >= 3 && tok[2][0] == 's') {
+        f.ph[0].splitk = std::max(1, atoi(tok[2].c_str() + 1));
+      }
+      return f;
+    }
+  }
+  for (const ConvShape& sh : kShapes) {
+    if (!allowed(sh)) continue;
+    for (int s : {1, 2, 3, 4, 6, 8, 12, 16, 32, 64}) {
+      if (s > 1 && (nk / s < 12 || nk < 24)) break;
+      const double c = single_cost(sh, M, N, nk, s, n_cu);
+      if (c < best.cost * 0.97) {
+        best.cost = c;
+        best.n = 1;
+        best.ph[0] = {sh.wide, sh.bm, 0, M, s};
+      }
+    }
+  }
+  for (const ConvShape& A : kShapes) {
+    if (!allowed(A)) continue;
+    const int ntA = (N + (A.wide ? 255 : 127)) / (A.wide ? 256 : 128);
+    const long tilesA = (long)((M + A.bm - 1) / A.bm) * ntA;
+    for (long R = 1; R * n_cu < tilesA; ++R) {
+      if (R * n_cu % ntA) continue;
+      const long m1 = R * n_cu / ntA * A.bm;
+      if (m1 >= M) break;
+      const double c1 = R * (nk * A.kt_us + A.tile_us);
+      for (const ConvShape& B : kShapes) {
+        if (!allowed(B)) continue;
+        const double c = c1 + single_cost(B, M - m1, N, nk, 1, n_cu) + 3.0;   // (+ the gap between two launches)
+        if (c < best.cost * 0.97) {
+          best.cost = c;
+          best.n = 2;
+          best.ph[0] = {A.wide, A.bm, 0, (int)m1, 1};
+          best.ph[1] = {B.wide, B.bm, (int)m1, M, 1};
+        }
+      }
+    }
+  }
+  return best;
+}
+
 // One encoder block.  Activations between blocks live in the P2 split layout when the fp16x2 kernel is in use
 // (in_split / out_split); fp32 NHWC otherwise.
 static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void* out, bool in_split, bool out_split,
@@ -821,26 +926,42 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
       a.stamp = (sl ? atoi(sl) == i : 1) ? 1 + (sw ? atoi(sw) : 0) : 0;
     }
     a.out_bytes = extent_of(p, out, (size_t)a.M * a.Cout * sizeof(float));
-    {  // 256 x 256 tiles (a third fewer staged bytes per flop) where they fill whole rounds of the chip: measured
-       // conv3 1400 -> 1204 us and conv3_1 1012 -> 922 us (1280 tiles = 5.0 rounds of 256 CUs), but conv4 / conv4_1
-       // +6 % (640 tiles = 2.5 rounds: the half-empty last round costs more than the saved bytes)
-      static const char* wenv = getenv("ODEVIO_WIDE");   // diagnostic: 0 = never, 1 = whenever Cout % 256 == 0
+    const int nk = cs.k * cs.k * cs.cin / 32;
+    static const char* legacy = getenv("ODEVIO_CONV_PLAN");   // diagnostic: "legacy" = round 1's rule (one shape per layer, 256-pixel tiles)
+    ConvPlanF plan{};
+    if (legacy && !strcmp(legacy, "legacy")) {
       const long wide_tiles = (long)((a.M + 255) / 256) * (a.Cout / 256);
       const double rounds = (double)wide_tiles / p->n_cu;
-      const bool fills = wide_tiles >= 2L * p->n_cu && rounds / std::ceil(rounds) >= 0.9;
-      a.wide = a.Cout % 256 == 0 && (wenv ? atoi(wenv) != 0 : fills);
+      const bool wide = a.Cout % 256 == 0 && wide_tiles >= 2L * p->n_cu && rounds / std::ceil(rounds) >= 0.9;
+      plan.n = 1;
+      plan.ph[0] = {wide, 256, 0, a.M, wide ? 1 : pick_splitk_h(a.M, a.Cout, nk)};
+    } else {
+      plan = plan_f16x2(i, a.M, a.Cout, nk, p->n_cu, a.off32 != 0);
     }
-    const int nk = cs.k * cs.k * cs.cin / 32;
-    a.splitk = a.wide ? 1 : pick_splitk_h(a.M, a.Cout, nk);
-    a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
-    a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
-    if (a.splitk > 1) {
-      int rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout);
-      if (rc) return rc;
-      a.partial = p->partial.p;
-      a.partial_bytes = p->partial.n * sizeof(float);
+    {
+      static const bool print = getenv("ODEVIO_CONV_PLAN_PRINT") != nullptr;   // diagnostic: each layer's plan, once
+      static bool printed[16] = {};
+      if (print && !printed[i]) {
+        printed[i] = true;
+        for (int ph = 0; ph < plan.n; ++ph)
+          fprintf(stderr, "odevio conv plan: layer %d (M %d, Cout %d, %d K-tiles) phase %d: %d x %d tiles, pixels %d..%d, split-K %d (model %.0f us)\n", i,
+                  a.M, a.Cout, nk, ph, plan.ph[ph].bm, plan.ph[ph].wide ? 256 : 128, plan.ph[ph].m_begin, plan.ph[ph].m_end, plan.ph[ph].splitk, plan.cost);
+      }
     }
-    HIPCHK(launch_conv_f16x2(a, st));
+    for (int ph = 0; ph < plan.n; ++ph) {
+      const ConvPhase& f = plan.ph[ph];
+      a.wide = f.wide; a.bm = f.bm; a.m_begin = f.m_begin; a.m_end = f.m_end;
+      a.splitk = f.splitk;
+      a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
+      a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
+      if (a.splitk > 1) {
+        int rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout);
+        if (rc) return rc;
+        a.partial = p->partial.p;
+        a.partial_bytes = p->partial.n * sizeof(float);
+      }
+      HIPCHK(launch_conv_f16x2(a, st));
+    }
     return 0;
   }
   if (out_split) return fail(ODEVIO_ERR_BAD_ARG, "conv_block: fp32-input blocks write fp32");

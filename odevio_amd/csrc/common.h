@@ -86,6 +86,8 @@ struct ConvSplitArgs {
   int ld_out;           // row stride (floats) of an fp32 output (out_split = 0)
   int splitk, ktiles_per_split;
   int xcd_map;
+  int bm;               // pixels per tile: 256 (0 = default) or 192
+  int m_begin, m_end;   // pixels of the layer this launch covers (m_end = 0: all M); split-K slabs are laid out for all M
 };
 
 // conv1 of the FlowNetS stack, reading frame pairs in place from img [B][S][3][H][W]

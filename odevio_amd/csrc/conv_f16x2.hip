@@ -33,9 +33,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#define HBM_ 256            // pixels per tile
 #define HROW 128            // bytes of one (row, K-tile) block: 2 pieces x 32 channels x 2 B
-#define HA_BYTES (HBM_ * HROW)
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -45,22 +43,32 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Why the wide tile exists: with one MFMA per product (TERMS = 1) the 256 x 128 kernel still needs 4.0 of its 6.3 ms -
 // the L2 -> LDS staging stream (52 GB per forward, ~13 TB/s) is a second ceiling right under the MFMA/power one, and a
 // 256 x 256 tile moves a third fewer bytes per flop.
-template <int BN> struct HTile {
-  static constexpr int STAGE = (HBM_ + BN) * HROW;        // bytes per stage
+// Pixel extent BM = 256, or 192 (three 16-pixel blocks per wave instead of four): the planner (api.hip) mixes the two so
+// that a layer's tiles fill WHOLE rounds of the chip - e.g. conv4's 90,112 pixels x 512 channels = 2 rounds of 256 x 256
+// tiles + 1 round of 192 x 256 tiles, instead of 5.5 (= 6) rounds of 256 x 128 tiles.
+template <int BN, int BM = 256> struct HTile {
+  static constexpr int HA = BM * HROW;                    // bytes of the pixel rows of a stage
+  static constexpr int STAGE = (BM + BN) * HROW;          // bytes per stage
   static constexpr int NSTAGE = BN == 128 ? 3 : 2;
   static constexpr int LOOKAHEAD = NSTAGE - 1;            // tiles of DMA in flight beyond the one being multiplied
+  static constexpr int NI = BM / 64;                      // 16-pixel blocks per wave = pixel-row DMAs per wave and K-tile (8 rows each)
   static constexpr int BDMA = BN / 64;                    // weight-row DMAs per wave and K-tile (8 rows each)
-  static constexpr int DMAS = 4 + BDMA;                   // DMAs per wave and K-tile
-  // 144 KB / 130 KB: the stages, or (wide tile) the epilogue's staging area of 128 pixels x (1024 + 16) bytes if larger
-  static constexpr int LDS = NSTAGE * STAGE > 128 * (BN * 4 + 16) || BN == 128 ? NSTAGE * STAGE : 128 * (BN * 4 + 16);
+  static constexpr int DMAS = NI + BDMA;                  // DMAs per wave and K-tile
+  // epilogue through LDS: BN = 128 the whole tile in one pass, BN = 256 two passes of up to two 16-pixel blocks per wave
+  static constexpr int NPASS = BN == 128 ? 1 : 2;
+  static constexpr int IPP = (NI + NPASS - 1) / NPASS;    // 16-pixel blocks of a wave per pass
+  static constexpr int PASS_PX = 64 * IPP;                // staged pixels per pass
+  static constexpr int EPI = PASS_PX * (BN * 4 + 16);
+  static constexpr int LDS = NSTAGE * STAGE > EPI ? NSTAGE * STAGE : EPI;   // 144 KB / 130 KB (BM = 256)
 };
 
 // TERMS = 3: the fp32-grade product described above.  TERMS = 1 (ODEVIO_CONV_MATH=f16, outside the fp32 parity claim):
 // only h_w h_x, i.e. plain fp16 operands (11-bit significands) with fp32 accumulation - the reduced-precision mode of
 // BASELINE configs[2]; same layout, same kernel, a third of the MFMAs.
-template <int TERMS, int BN, bool O32>
+template <int TERMS, int BN, bool O32, int BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16x2_kernel(ConvSplitArgs a) {
-  typedef HTile<BN> T;
+  typedef HTile<BN, BM> T;
+  constexpr int NI = T::NI;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // T::LDS bytes
 
   const int tid = threadIdx.x;
@@ -77,8 +85,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     mt_idx = xcd * chunk + slot / NT;
     nt_idx = slot - (slot / NT) * NT;
   }
-  if (mt_idx * HBM_ >= a.M) return;
-  const int m0 = mt_idx * HBM_;
+  // this launch covers pixels m_begin .. m_end - 1 of the layer (a layer may be split between two tile shapes)
+  const int m0 = a.m_begin + mt_idx * BM;
+  if (m0 >= a.m_end) return;
   const int n0 = nt_idx * BN;
 #ifdef ODEVIO_STAMPS   // diagnostic build (make STAMPS=1): phase stamps of workgroup 0 into the words behind the status (odevio_debug_stamps)
   const bool stamper = a.stamp && (int)(blockIdx.y * gridDim.x + blockIdx.x) == a.stamp - 1 && blockIdx.z == 0 && tid == 0;
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 
   // ---- loader role.  One DMA instruction = 8 rows x 8 pieces of 16 B; lane l brings LDS slot (l & 7) of row
-  // (l >> 3), which holds source piece slot ^ ((row >> 1) & 7).  Wave w stages pixel rows 32w .. 32w+31 (4 DMAs) and
+  // (l >> 3), which holds source piece slot ^ ((row >> 1) & 7).  Wave w stages pixel rows (BM/8)w .. (BM/8)w + BM/8 - 1 (NI DMAs) and
   // weight rows (BN/8)w .. (BN/8)w + BN/8 - 1 (BDMA DMAs) of every K-tile.
   const int groups = a.Cin >> 5;            // 32-channel groups per pixel
   const int taps = a.KH * a.KW;
@@ -101,30 +110,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // "outside" is the offset of the zero bytes that follow the activations inside the same allocation.  Per DMA that is
   // a bit test, a select and an add on 32-bit registers - the 64-bit form below needs two range compares, two 64-bit
   // selects and a 64-bit add, and the DMA-issue work of this kernel is what the MFMAs wait for.
-  const unsigned char* a_row[4];
-  int a_hi0[4], a_wi0[4];
-  int a_poff[4];                            // byte offset of this lane's source piece inside the 128-byte block
-  unsigned a_off[4], a_mask[4];
-  unsigned a_zoff[2] = {0, 0};              // zero-tail offsets: the source piece of row q only depends on q & 1
+  const unsigned char* a_row[NI];
+  int a_hi0[NI], a_wi0[NI];
+  int a_poff[NI];                           // byte offset of this lane's source piece inside the 128-byte block
+  unsigned a_off[NI], a_mask[NI];
+  // zero-tail offsets: the source piece of a row only depends on (row >> 1) & 7 = (4 (q + (BM/32) wave) + (lr >> 1)) & 7,
+  // i.e. on the parity of q (BM = 256) or of q + wave (BM = 192): two registers, picked by a select, not by an index
+  unsigned a_zoff0 = 0, a_zoff1 = 0;
+  const bool zflip = BM == 192 && (wave & 1);
   const int HoWo = a.Ho * a.Wo;
   // (image, row, column) of this lane's first pixel row by division; its other three rows are 8, 16, 24 pixels further
   // on and follow by carries (this set-up is on every tile's critical path: nothing is in flight until it is done)
   int p_img, p_ho, p_wo;
   {
-    const int m = m0 + 32 * wave + lr;
+    const int m = m0 + (BM / 8) * wave + lr;
     p_img = m / HoWo;
     const int rem = m - p_img * HoWo;
     p_ho = rem / a.Wo;
     p_wo = rem - p_ho * a.Wo;
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = 32 * wave + 8 * q + lr;   // row of the pixel tile
+  for (int q = 0; q < NI; ++q) {
+    const int r = (BM / 8) * wave + 8 * q + lr;   // row of the pixel tile
     a_poff[q] = (lslot ^ ((r >> 1) & 7)) * 16;
     const int m = m0 + r;
     a_off[q] = 0; a_mask[q] = 0;
-    if (q < 2) a_zoff[q] = a.in_zero_off + a_poff[q];   // rows 8q + lr and 8(q+2) + lr share (row >> 1) & 7
-    if (m < a.M) {
+    if (q == 0) (zflip ? a_zoff1 : a_zoff0) = a.in_zero_off + a_poff[q];   // rows 8q + lr and 8(q+2) + lr share (row >> 1) & 7
+    if (q == 1) (zflip ? a_zoff0 : a_zoff1) = a.in_zero_off + a_poff[q];
+    if (m < a.m_end) {
       const int img = p_img, ho = p_ho, wo = p_wo;
       a_hi0[q] = ho * a.stride - a.pad;
       a_wi0[q] = wo * a.stride - a.pad;
@@ -212,11 +225,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const unsigned char* zw = w_b + a.w_zero_off;
       (void)zin; (void)zw;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned off = (a_mask[q] & bit) ? a_off[q] + (unsigned)t_aoff : a_zoff[q & 1];
+      for (int q = 0; q < NI; ++q) {
+        const unsigned zoff = ((q & 1) != 0) != zflip ? a_zoff1 : a_zoff0;
+        const unsigned off = (a_mask[q] & bit) ? a_off[q] + (unsigned)t_aoff : zoff;
         const unsigned char* pa = in_b + off;
         pa = AUDIT_SRC(pa, 16, in_b, a.in_bytes, zin, a.status, AK_CONV_A);
-        __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + (32 * wave + 8 * q) * HROW), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + ((BM / 8) * wave + 8 * q) * HROW), 16, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < T::BDMA; ++q) {
@@ -224,29 +238,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned off = BN == 256 ? b_off[q] + (unsigned)t_boff : b_off[q] + ((unsigned)t_boff & b_sel[q]);
         const unsigned char* pb = w_b + off;
         pb = AUDIT_SRC(pb, 16, w_b, a.w_bytes, zw, a.status, AK_CONV_B);
-        __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + HA_BYTES + (8 * T::BDMA * wave + 8 * q) * HROW), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + T::HA + (8 * T::BDMA * wave + 8 * q) * HROW), 16, 0, 0);
       }
       return;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NI; ++q) {
       const bool ok = (unsigned)(a_hi0[q] + t_kh) < (unsigned)a.Hi && (unsigned)(a_wi0[q] + t_kw) < (unsigned)a.Wi;
       const unsigned char* pa = ok ? a_row[q] + t_aoff : zero_b + a_poff[q];
       pa = AUDIT_SRC(pa, 16, in_b, a.in_bytes, zero_b, a.status, AK_CONV_A);
-      __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + (32 * wave + 8 * q) * HROW), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(dst + ((BM / 8) * wave + 8 * q) * HROW), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < T::BDMA; ++q) {
       const unsigned char* pb = b_row[q] ? b_row[q] + t_boff : zero_b + b_poff[q];
       pb = AUDIT_SRC(pb, 16, w_b, a.w_bytes, zero_b, a.status, AK_CONV_B);
-      __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + HA_BYTES + (8 * T::BDMA * wave + 8 * q) * HROW), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(dst + T::HA + (8 * T::BDMA * wave + 8 * q) * HROW), 16, 0, 0);
     }
   };
 
   constexpr int NB = BN / 32;   // 16-channel blocks per wave: 4 or 8
-  f32x4 acc[4][NB];   // [pixel block of 16][channel block of 16]
+  f32x4 acc[NI][NB];   // [pixel block of 16][channel block of 16]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -255,20 +269,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // rows, so the permutation only depends on fi.  Conflict-free per ds_read_b128 lane group.
   const int fi = lane & 15, fh = lane >> 4;
   const int fsw = (fi >> 1) & 7;
-  const int a_base = (wm * 64 + fi) * HROW;
-  const int b_base = HA_BYTES + (wn * (BN / 2) + fi) * HROW;
+  const int a_base = (wm * (BM / 4) + fi) * HROW;   // (wave row bases are multiples of 16 rows for both BM)
+  const int b_base = T::HA + (wn * (BN / 2) + fi) * HROW;
 
   // D rows = output channels (weights are the MFMA's A operand), D columns = pixels: a lane ends up with 4
   // consecutive channels of one pixel per register group (one vector store each in the epilogue).
   auto multiply = [&](int stage) __attribute__((always_inline)) {
     const unsigned char* Ab = lds + stage * T::STAGE + a_base;
     const unsigned char* Bb = lds + stage * T::STAGE + b_base;
-    f16x8 xf[4][2];   // [block][piece]
+    f16x8 xf[NI][2];   // [block][piece]
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int off = ((4 * p + fh) ^ fsw) * 16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i][p] = *reinterpret_cast<const f16x8*>(Ab + i * 16 * HROW + off);
+      for (int i = 0; i < NI; ++i) xf[i][p] = *reinterpret_cast<const f16x8*>(Ab + i * 16 * HROW + off);
     }
     constexpr int PW[3] = {1, 0, 0};   // l_w h_x, h_w l_x, h_w h_x: small contributions first
     constexpr int PX[3] = {0, 1, 0};
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int n = 0; n < 4; ++n) wf[n][p] = *reinterpret_cast<const f16x8*>(Bb + (4 * nh + n) * 16 * HROW + off);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -368,9 +382,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int PXS = PXB + 16;                     // its stride in LDS
     // BN = 128: the whole tile in one pass.  Wide tile (256 KB of output, 130 KB of LDS): two passes, and in each EVERY wave
     // stages half of its own pixel rows (i = 2 pass, 2 pass + 1), so that all eight waves convert and write in both passes
-    constexpr int PASS_PX = BN == 128 ? HBM_ : 128;
-    constexpr int NPASS = HBM_ / PASS_PX;
-    constexpr int IPP = 4 / NPASS;                    // 16-pixel blocks of a wave per pass
+    // (BM = 192: three blocks per wave - one pass of three, or a pass of two and a pass of one)
+    constexpr int PASS_PX = T::PASS_PX, NPASS = T::NPASS, IPP = T::IPP;
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int gpp = a.Cout >> 5;                      // 128-byte blocks per pixel in memory
     unsigned absmax = 0;                              // largest |x| bit pattern this lane produced
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int ii = 0; ii < IPP; ++ii) {
           const int i = pass * IPP + ii;
+          if (i >= NI) continue;
           const int pl = wm * (16 * IPP) + ii * 16 + fi;                    // pixel inside the pass
 #pragma unroll
           for (int nb4 = 0; nb4 < NB; ++nb4) {
@@ -394,7 +408,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             x = __builtin_elementwise_max(x, x * a.slope);
             const f16x4 h = __builtin_convertvector(x, f16x4);
             const f16x4 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), f16x4);
-            if ((n0 + nl < a.Cout) && (m0 + wm * 64 + i * 16 + fi < a.M)) {
+            if ((n0 + nl < a.Cout) && (m0 + wm * (BM / 4) + i * 16 + fi < a.m_end)) {
               const u32x4 xb = __builtin_bit_cast(u32x4, x) & 0x7fffffffu;
               absmax = max(absmax, max(max(xb[0], xb[1]), max(xb[2], xb[3])));
             }
@@ -412,9 +426,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int o = (it * 512 + tid) * 16;          // byte offset inside the pass, memory order
         const int pl = o / PXB, within = o - pl * PXB;
         // pixel of the tile behind staged pixel pl: wave row pl / (16 IPP), its blocks pass * IPP ..
-        const int m = m0 + (pl / (16 * IPP)) * 64 + pass * (16 * IPP) + (pl & (16 * IPP - 1));
+        const int wrow = pass * (16 * IPP) + pl % (16 * IPP);               // row inside its wave's BM / 4 rows
+        const int m = m0 + (pl / (16 * IPP)) * (BM / 4) + wrow;
         const u32x4 v = *reinterpret_cast<const u32x4*>(lds + pl * PXS + within);
-        if (m < a.M && (n0 >> 5) + (within >> 7) < gpp) {
+        if (wrow < BM / 4 && m < a.m_end && (n0 >> 5) + (within >> 7) < gpp) {
           unsigned char* dst = outb + ((size_t)m * gpp + (n0 >> 5)) * 128 + within;
           if (AUDIT_DST_OK(dst, 16, a.out, a.out_bytes, a.status, AK_CONV_OUT)) *reinterpret_cast<u32x4*>(dst) = v;
         }
@@ -427,9 +442,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     range_bad = absmax > 0x477fe000u;                 // bits of 65504.0f: anything above (incl. inf / NaN) cannot be carried as fp16 pieces
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + fi;
-      if (m >= a.M) continue;
+    for (int i = 0; i < NI; ++i) {
+      const int m = m0 + wm * (BM / 4) + i * 16 + fi;
+      if (m >= a.m_end) continue;
 #pragma unroll
       for (int nb4 = 0; nb4 < NB; ++nb4) {
         const int n = n0 + wn * (BN / 2) + nb4 * 16 + 4 * fh;  // first of 4 consecutive channels; Cout % 32 == 0
@@ -483,20 +498,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16x2_kernel(ConvSplitArgs 
   if (range_bad) a.status[ODEVIO_STATUS_RANGE] = 1;
 }
 
-template <int TERMS, int BN, bool O32>
+template <int TERMS, int BN, bool O32, int BM>
 static hipError_t launch_tile_o(const ConvSplitArgs& a, dim3 grid, hipStream_t st) {
   static unsigned long long attr_mask = 0;   // the dynamic-LDS attribute is per device
+  constexpr int lds_bytes = HTile<BN, BM>::LDS;
   if (first_use_on_device(attr_mask)) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<TERMS, BN, O32>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, HTile<BN>::LDS);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<TERMS, BN, O32, BM>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((conv_f16x2_kernel<TERMS, BN, O32>), grid, dim3(512), HTile<BN>::LDS, st, a);
+  hipLaunchKernelGGL((conv_f16x2_kernel<TERMS, BN, O32, BM>), grid, dim3(512), lds_bytes, st, a);
   return hipSuccess;
 }
 template <int TERMS, int BN>
 static hipError_t launch_tile(const ConvSplitArgs& a, dim3 grid, hipStream_t st) {
-  return a.off32 ? launch_tile_o<TERMS, BN, true>(a, grid, st) : launch_tile_o<TERMS, BN, false>(a, grid, st);
+  if (a.bm == 192) return launch_tile_o<TERMS, BN, true, 192>(a, grid, st);   // (192-pixel tiles exist in the 32-bit addressing form only)
+  return a.off32 ? launch_tile_o<TERMS, BN, true, 256>(a, grid, st) : launch_tile_o<TERMS, BN, false, 256>(a, grid, st);
 }
 
 // Host-side check of what the kernel and its grid assume, at every launch (cheap; the kernel's DMAs are not
@@ -504,6 +521,9 @@ static hipError_t launch_tile(const ConvSplitArgs& a, dim3 grid, hipStream_t st)
 static bool conv_args_consistent(const ConvSplitArgs& a) {
   if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || a.KH < 1 || a.KW < 1 || a.stride < 1) return false;
   if (a.wide && a.Cout % 256) return false;
+  if (a.bm != 256 && !(a.bm == 192 && a.off32)) return false;
+  if (a.m_begin < 0 || a.m_begin >= a.m_end || a.m_end > a.M) return false;
+  if ((a.m_begin != 0 || a.m_end != a.M) && a.splitk > 1) return false;   // the split-K combine runs over the whole layer
   if ((size_t)a.N * a.Ho * a.Wo != (size_t)a.M) return false;
   if ((a.Hi + 2 * a.pad - a.KH) / a.stride + 1 != a.Ho || (a.Wi + 2 * a.pad - a.KW) / a.stride + 1 != a.Wo) return false;
   const size_t nk = (size_t)a.KH * a.KW * (a.Cin / 32);
@@ -525,13 +545,15 @@ static bool conv_args_consistent(const ConvSplitArgs& a) {
 
 hipError_t launch_conv_f16x2(const ConvSplitArgs& a_in, hipStream_t st) {
   ConvSplitArgs a = a_in;
+  if (a.bm == 0) a.bm = 256;
+  if (a.m_end == 0) { a.m_begin = 0; a.m_end = a.M; }   // the whole layer
   if (!conv_args_consistent(a)) return hipErrorInvalidValue;
 #ifdef ODEVIO_AUDIT
   // self-test of the audit itself (a checker that never fires proves nothing): declare the input 256 bytes shorter than
   // it is, so the DMA of the last pixel's last channel group must be caught (tests/test_gpu_parity.py)
   if (getenv("ODEVIO_AUDIT_SELFTEST")) a.in_bytes -= 256;
 #endif
-  const int mt = (a.M + HBM_ - 1) / HBM_;
+  const int mt = (a.m_end - a.m_begin + a.bm - 1) / a.bm;
   a.xcd_map = mt >= 16;
   const int bn = a.wide ? 256 : 128;
   dim3 grid(a.xcd_map ? (mt + 7) / 8 * 8 : mt, (a.Cout + bn - 1) / bn, a.splitk > 1 ? a.splitk : 1);

@@ -78,6 +78,48 @@ def test_image_encoder_ragged_sizes(dev):
     assert_close(model.image_encoder(img.cuda()), oc.image_encoder(sd, img), what="fv")
 
 
+@pytest.mark.parametrize("force", [
+    "1:n192,2:n192,3:n192,4:n192,5:n192,6:n192,7:n192,8:n192",          # 192 x 128 tiles everywhere
+    "1:n,2:w192,3:w192,4:w192,5:w192,6:w192,7:w192,8:w192",              # 192 x 256 tiles wherever Cout % 256 == 0
+    "2:w,3:w,4:w:s2,5:w192:s3,6:n:s4,7:w:s2,8:w192:s2",                   # split-K on every shape
+])
+def test_every_tile_shape_of_the_fp16x2_kernel(dev, monkeypatch, force):
+    # the planner picks among four tile shapes per layer; forced here so that small inputs reach all of them (ragged
+    # image: partial tiles, rows past M, the 192-pixel tile's uneven epilogue passes)
+    opt = default_opt(img_h=72, img_w=136)
+    model, sd = make_model(opt, seed=23)
+    img = synth.images(2, 4, 72, 136, seed=7)
+    ref = oc.image_encoder(sd, img)
+    monkeypatch.setenv("ODEVIO_CONV_FORCE", ",".join(f"{i}:n" for i in range(1, 9)))   # 256 x 128 tiles, no split-K
+    base = model.image_encoder(img.cuda())
+    monkeypatch.setenv("ODEVIO_CONV_FORCE", force)
+    got = model.image_encoder(img.cuda())
+    model.check()
+    assert_close(got, ref, what="fv, forced tile shapes")
+    if ":s" not in force:   # same K order per output, whatever the tile: bit-identical
+        assert torch.equal(got, base)
+
+
+def test_two_phase_tile_plan_matches_single_phase(dev, monkeypatch):
+    # a layer split between two tile shapes (R full rounds of the chip in one, the remaining pixels in another), at a size
+    # where the split falls inside the batch: conv2 of 8 frame pairs = 65,536 pixels; one round of 192 x 128 tiles covers
+    # n_cu x 192 of them (49,152 on 256 CUs), 256 x 128 tiles take the rest.  (The bench batch's own two-phase plans run in
+    # test_baseline_config1_full_batch.)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    if n_cu * 192 >= 65536:
+        pytest.skip("device too large for the split to fall inside this batch")
+    opt = default_opt()
+    model, sd = make_model(opt, seed=24)
+    img = synth.images(2, 5, 256, 512, seed=8)
+    monkeypatch.setenv("ODEVIO_CONV_FORCE", "1:n")
+    single = model.image_encoder(img.cuda())
+    monkeypatch.setenv("ODEVIO_CONV_FORCE", "1:n192:1:n")
+    two = model.image_encoder(img.cuda())
+    model.check()
+    assert torch.equal(two, single)
+    assert_close(two, oc.image_encoder(sd, img), what="fv, two-phase plan")
+
+
 def test_image_encoder_golden_full_size(dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "image_encoder_full.npz"))
     opt = default_opt()
