@@ -785,7 +785,8 @@ static double single_cost(const ConvShape& sh, long M, int N, int nk, int s, int
   const long tiles = ((M + sh.bm - 1) / sh.bm) * ((N + bn - 1) / bn) * s;
   const double rounds = std::ceil((double)tiles / n_cu);
   double cost = rounds * (std::ceil((double)nk / s) * sh.kt_us + sh.tile_us);
-  if (s > 1) cost += (s + 1.0) * M * N * 4.0 / 4.0e6 + 8.0;   // slabs written and read at ~4 TB/s, one more launch
+  if (s > 1) cost += (s + 1.0) * M * N * 4.0 / 2.0e6 + 15.0;  // slabs written and read (~2 TB/s effective beside the tiles), one more launch
+                                                                // (measured: conv6 as 256 x 256 split-K 3 is 0.07 ms slower than 192 x 128 unsplit)
   return cost;
 }
 
