@@ -169,6 +169,8 @@ static int ensure(DevBuf& b, size_t n) {
   b.n = 0;
   HIPCHK(hipMalloc((void**)&b.p, n * sizeof(float) + ODEVIO_ZERO_PAGE_BYTES));
   HIPCHK(hipMemset(b.p + n, 0, ODEVIO_ZERO_PAGE_BYTES));
+  static const bool zero_all = getenv("ODEVIO_ZERO_BUFFERS") != nullptr;   // timing experiments that skip a producer's stores
+  if (zero_all) HIPCHK(hipMemset(b.p, 0, n * sizeof(float)));
   b.n = n;
   return 0;
 }
