@@ -177,6 +177,30 @@ int odevio_ode_rnn_bwd(odevio_plan* plan, const float* fused, const float* ts, c
  * n_rows = B*P rows; grad_poses [n_rows,6] = d loss3[0] / d poses, or NULL. */
 int odevio_pose_loss(const float* poses, const float* gts, int32_t n_rows, float* loss3, float* grad_poses, void* stream);
 
+/* FusionModule backward (reference src/models/FusionModule.py:17-23; autograd in scripts/train_model.py:78): fv [P,v], fi [P,i],
+ * grad_fused [P,v+i] -> grad_fv [P,v], grad_fi [P,i] (either may be NULL) and, for fuse_method "soft", the gradients of
+ * Pose_net.fuse.net.0.weight / .bias named in `grads` (device pointers, reference shapes).  ("hard" is not a device
+ * fusion mode: the host-side wrapper refuses its backward.) */
+int odevio_fuse_bwd(odevio_plan* plan, const float* fv, const float* fi, int32_t P, const float* grad_fused, float* grad_fv,
+                    float* grad_fi, const odevio_tensor* grads, int32_t n_grads, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) as the reference calls it before optimizer.step()
+ * (scripts/train_model.py:84): the total L2 norm over the n gradient tensors and the factor min(1, max_norm / (norm + 1e-6)),
+ * written to the device pair norm_coef = {norm, factor}.  Nothing is scaled here and nothing returns to the host:
+ * odevio_adam_step multiplies by the factor. */
+int odevio_grad_clip(odevio_plan* plan, const odevio_tensor* grads, int32_t n_grads, float max_norm, float* norm_coef, void* stream);
+
+/* One torch.optim.Adam update of one parameter tensor, the optimizer the reference builds over Pose_net's parameters
+ * (utils/utils.py:115-130: betas (0.9, 0.999), eps 1e-8, weight_decay added to the gradient, amsgrad off):
+ * param, exp_avg, exp_avg_sq are updated in place; `step` counts from 1; norm_coef = the pair of odevio_grad_clip or NULL. */
+int odevio_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int32_t step, const float* norm_coef, void* stream);
+
+/* After an optimizer step: re-reads the parameters of Pose_net (fusion, regressor, ODEFunc, RNN; every key of the
+ * reference's Pose_net state_dict, device pointers) into the plan's kernel layouts, in place.  The encoders are not
+ * touched: the reference's optimizer does not hold their parameters either (utils/utils.py:116-119). */
+int odevio_plan_update(odevio_plan* plan, const odevio_tensor* weights, int32_t n_weights, void* stream);
+
 /* The Neural-CDE vector field for one piece of the control path (CDEFunc.forward, reference src/models/ODEFunc.py:76-83,
  * contracted with dX/dt as torchcde's cdeint does): z [B,H], obs [B,L,1+F], seg = piece 0 .. 2L-3 of the rectilinear
  * path (even: the time channel moves, odd: the features) -> out [B,H] = reshape(CDEFunc(z), [B,H,H+1]) . dX/dt(seg).

@@ -25,6 +25,7 @@ SYMBOLS = [
     "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
     "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func", "odevio_cde_last_ms",
     "odevio_ode_rnn_bwd", "odevio_pose_loss", "odevio_resize_u8", "odevio_resize_table",
+    "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update",
 ]
 
 
@@ -107,6 +108,11 @@ def load():
     lib.odevio_cde_last_ms.argtypes = [vp, fp]
     lib.odevio_ode_rnn_bwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_pose_loss.argtypes = [fp, fp, i32, fp, fp, vp]
+    f32 = ctypes.c_float
+    lib.odevio_fuse_bwd.argtypes = [vp, fp, fp, i32, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
+    lib.odevio_grad_clip.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, f32, fp, vp]
+    lib.odevio_adam_step.argtypes = [fp, fp, fp, fp, ctypes.c_int64, f32, f32, f32, f32, f32, i32, fp, vp]
+    lib.odevio_plan_update.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_resize_table.argtypes = [i32, i32, vp, vp, vp, i32]
     lib.odevio_resize_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.odevio_cde_func.argtypes = [vp, fp, fp, i32, i32, i32, fp, vp]

@@ -99,7 +99,7 @@ struct odevio_plan {
   int head_k = 0;
   float *imu_w[3] = {}, *imu_s[3] = {}, *imu_h[3] = {};
   float *proj_w = nullptr, *proj_b = nullptr;
-  float *fuse_w = nullptr, *fuse_b = nullptr;
+  float *fuse_w = nullptr, *fuse_b = nullptr, *fuse_w_t = nullptr;
   float *reg_w0 = nullptr, *reg_b0 = nullptr, *reg_w2 = nullptr, *reg_b2 = nullptr;
   // integrator
   int nlin = 0;
@@ -119,7 +119,7 @@ struct odevio_plan {
   bool status_pending = false;
   // backward (train.hip): plain and transposed copies of the ODEFunc / RNN / regressor weights, workspace
   TrainModel train = {};
-  DevBuf train_ws, train_log;
+  DevBuf train_ws, train_log, train_aux;   // train_aux: fusion backward / gradient-norm partials
   // Neural-CDE path (model_type cde)
   CdeModel cde = {};
   float *cde_init_w = nullptr, *cde_init_b = nullptr;
@@ -153,8 +153,10 @@ static int dev_alloc(odevio_plan* p, void** out, size_t bytes) {
   return 0;
 }
 static int upload(odevio_plan* p, float** out, const std::vector<float>& h, hipStream_t st) {
-  int rc = dev_alloc(p, (void**)out, h.size() * sizeof(float));
-  if (rc) return rc;
+  if (*out == nullptr) {   // (a non-null target is a buffer of the same size from an earlier load: odevio_plan_update)
+    int rc = dev_alloc(p, (void**)out, h.size() * sizeof(float));
+    if (rc) return rc;
+  }
   HIPCHK(hipMemcpyAsync(*out, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));  // h may be a temporary
   return 0;
@@ -321,7 +323,7 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side, &p->train_ws, &p->train_log})
+                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side, &p->train_ws, &p->train_log, &p->train_aux})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
@@ -362,6 +364,120 @@ static int validate(const odevio_config& c) {
                 F, c.ode_hidden_dim, INTEG_KMAX);
   if (c.v_f_len % 4 || c.i_f_len % 4) return fail(ODEVIO_ERR_UNSUPPORTED, "feature lengths must be multiples of 4");
   if (c.ode_substeps < 1) return fail(ODEVIO_ERR_BAD_ARG, "ode_substeps must be >= 1");
+  return 0;
+}
+
+// The parameters of Pose_net (fusion, regressor, ODEFunc, RNN stack) in the layouts the kernels read: called by
+// odevio_plan_create, and again by odevio_plan_update after an optimizer step changed them (buffers are reused).
+static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
+  const int F = p->F;
+  int rc;
+  std::vector<float> w, t, bias;
+#define PN(x)            \
+  do {                   \
+    rc = (x);            \
+    if (rc) return rc;   \
+  } while (0)
+  // ---- fusion, regressor
+  if (p->cfg.fuse_method == ODEVIO_FUSE_SOFT) {
+    PN(wt.get("Pose_net.fuse.net.0.weight", (int64_t)F * F, w));
+    PN(upload(p, &p->fuse_w, w, st));
+    PN(upload(p, &p->fuse_w_t, transposed(w, F, F), st));   // backward: g_c += g_w W
+    PN(wt.get("Pose_net.fuse.net.0.bias", F, bias));
+    PN(upload(p, &p->fuse_b, bias, st));
+  }
+  PN(wt.get("Pose_net.regressor.0.weight", (int64_t)128 * F, w));
+  PN(upload(p, &p->reg_w0, w, st));
+  {
+    float* wt0 = const_cast<float*>(p->train.reg_w0_t);
+    PN(upload(p, &wt0, transposed(w, 128, F), st));
+    p->train.reg_w0_t = wt0;
+  }
+  PN(wt.get("Pose_net.regressor.0.bias", 128, bias));
+  PN(upload(p, &p->reg_b0, bias, st));
+  PN(wt.get("Pose_net.regressor.2.weight", (int64_t)6 * 128, w));
+  PN(upload(p, &p->reg_w2, w, st));
+  PN(wt.get("Pose_net.regressor.2.bias", 6, bias));
+  PN(upload(p, &p->reg_b2, bias, st));
+  // ---- ODEFunc (column-sharded)
+  if (p->cfg.model_type == ODEVIO_MODEL_ODE_RNN) {
+    p->nlin = p->cfg.ode_fn_num_layers + 1;
+    p->dims[0] = F;
+    for (int l = 1; l < p->nlin; ++l) p->dims[l] = p->cfg.ode_hidden_dim;
+    p->dims[p->nlin] = F;
+    for (int l = 0; l < p->nlin; ++l) {
+      const std::string pre = "Pose_net.ode_func.net." + std::to_string(2 * l);
+      const int N = p->dims[l + 1], K = p->dims[l];
+      PN(wt.get(pre + ".weight", (int64_t)N * K, w));
+      shard_columns(w, N, {K}, t);
+      PN(upload(p, &p->ode_w[l], t, st));
+      {
+        float *pw = const_cast<float*>(p->train.ode_w[l]), *pwt = const_cast<float*>(p->train.ode_w_t[l]);
+        PN(upload(p, &pw, w, st));
+        PN(upload(p, &pwt, transposed(w, N, K), st));
+        p->train.ode_w[l] = pw;
+        p->train.ode_w_t[l] = pwt;
+      }
+      PN(wt.get(pre + ".bias", N, bias));
+      PN(upload(p, &p->ode_b[l], bias, st));
+    }
+  }
+  // ---- RNN stack: virtual columns over K = [input | hidden]
+  if (p->cfg.model_type != ODEVIO_MODEL_CDE) {
+    const int L = p->cfg.rnn_num_layers;
+    const bool gru = p->cfg.rnn_type == ODEVIO_RNN_GRU;
+    const int gates = gru ? 3 : 1;
+    const int V = gru ? 4 : 1;
+    p->rnn_vcols = V;
+    const int NCF = F / INTEG_MEMBERS;
+    std::vector<float> wih, whh, bih, bhh;
+    for (int l = 0; l < L; ++l) {
+      const std::string s = std::to_string(l);
+      PN(wt.get("Pose_net.rnn.weight_ih_l" + s, (int64_t)gates * F * F, wih));
+      PN(wt.get("Pose_net.rnn.weight_hh_l" + s, (int64_t)gates * F * F, whh));
+      PN(wt.get("Pose_net.rnn.bias_ih_l" + s, (int64_t)gates * F, bih));
+      PN(wt.get("Pose_net.rnn.bias_hh_l" + s, (int64_t)gates * F, bhh));
+      {   // plain copies for the backward (train.hip): [gates*F][F] and the transposes [F][gates*F]
+        float *a = const_cast<float*>(p->train.rnn_wih[l]), *at = const_cast<float*>(p->train.rnn_wih_t[l]), *b2 = const_cast<float*>(p->train.rnn_whh[l]),
+              *bt = const_cast<float*>(p->train.rnn_whh_t[l]), *c = const_cast<float*>(p->train.rnn_bih[l]), *d = const_cast<float*>(p->train.rnn_bhh[l]);
+        PN(upload(p, &a, wih, st));
+        PN(upload(p, &at, transposed(wih, gates * F, F), st));
+        PN(upload(p, &b2, whh, st));
+        PN(upload(p, &bt, transposed(whh, gates * F, F), st));
+        PN(upload(p, &c, bih, st));
+        PN(upload(p, &d, bhh, st));
+        p->train.rnn_wih[l] = a; p->train.rnn_wih_t[l] = at; p->train.rnn_whh[l] = b2; p->train.rnn_whh_t[l] = bt;
+        p->train.rnn_bih[l] = c; p->train.rnn_bhh[l] = d;
+      }
+      // virtual matrix [V*F][2F], row order: member-major, then v, then local unit
+      std::vector<float> vm((size_t)V * F * 2 * F, 0.f), vb((size_t)V * F, 0.f);
+      for (int m = 0; m < INTEG_MEMBERS; ++m)
+        for (int v = 0; v < V; ++v)
+          for (int ul = 0; ul < NCF; ++ul) {
+            const int u = m * NCF + ul;
+            float* dst = &vm[((size_t)(m * V + v) * NCF + ul) * 2 * F];
+            if (!gru) {
+              memcpy(dst, &wih[(size_t)u * F], F * sizeof(float));
+              memcpy(dst + F, &whh[(size_t)u * F], F * sizeof(float));
+              vb[u] = bih[u] + bhh[u];
+            } else if (v < 2) {  // r, z
+              memcpy(dst, &wih[((size_t)v * F + u) * F], F * sizeof(float));
+              memcpy(dst + F, &whh[((size_t)v * F + u) * F], F * sizeof(float));
+              vb[(size_t)v * F + u] = bih[(size_t)v * F + u] + bhh[(size_t)v * F + u];
+            } else if (v == 2) {  // n, input part
+              memcpy(dst, &wih[((size_t)2 * F + u) * F], F * sizeof(float));
+              vb[(size_t)2 * F + u] = bih[(size_t)2 * F + u];
+            } else {  // n, hidden part
+              memcpy(dst + F, &whh[((size_t)2 * F + u) * F], F * sizeof(float));
+              vb[(size_t)3 * F + u] = bhh[(size_t)2 * F + u];
+            }
+          }
+      shard_columns(vm, V * F, {F, F}, t);
+      PN(upload(p, &p->rnn_w[l], t, st));
+      PN(upload(p, &p->rnn_b[l], vb, st));
+    }
+  }
+#undef PN
   return 0;
 }
 
@@ -555,49 +671,8 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
     TRY(wt.get("Inertial_net.proj.bias", cfg->i_f_len, bias));
     TRY(upload(p, &p->proj_b, bias, st));
   }
-  // ---- fusion, regressor
-  if (cfg->fuse_method == ODEVIO_FUSE_SOFT) {
-    TRY(wt.get("Pose_net.fuse.net.0.weight", (int64_t)F * F, w));
-    TRY(upload(p, &p->fuse_w, w, st));
-    TRY(wt.get("Pose_net.fuse.net.0.bias", F, bias));
-    TRY(upload(p, &p->fuse_b, bias, st));
-  }
-  TRY(wt.get("Pose_net.regressor.0.weight", (int64_t)128 * F, w));
-  TRY(upload(p, &p->reg_w0, w, st));
-  {
-    float* wt0 = nullptr;
-    TRY(upload(p, &wt0, transposed(w, 128, F), st));
-    p->train.reg_w0_t = wt0;
-  }
-  TRY(wt.get("Pose_net.regressor.0.bias", 128, bias));
-  TRY(upload(p, &p->reg_b0, bias, st));
-  TRY(wt.get("Pose_net.regressor.2.weight", (int64_t)6 * 128, w));
-  TRY(upload(p, &p->reg_w2, w, st));
-  TRY(wt.get("Pose_net.regressor.2.bias", 6, bias));
-  TRY(upload(p, &p->reg_b2, bias, st));
-  // ---- ODEFunc (column-sharded)
-  if (cfg->model_type == ODEVIO_MODEL_ODE_RNN) {
-    p->nlin = cfg->ode_fn_num_layers + 1;
-    p->dims[0] = F;
-    for (int l = 1; l < p->nlin; ++l) p->dims[l] = cfg->ode_hidden_dim;
-    p->dims[p->nlin] = F;
-    for (int l = 0; l < p->nlin; ++l) {
-      const std::string pre = "Pose_net.ode_func.net." + std::to_string(2 * l);
-      const int N = p->dims[l + 1], K = p->dims[l];
-      TRY(wt.get(pre + ".weight", (int64_t)N * K, w));
-      shard_columns(w, N, {K}, t);
-      TRY(upload(p, &p->ode_w[l], t, st));
-      {
-        float *pw = nullptr, *pwt = nullptr;
-        TRY(upload(p, &pw, w, st));
-        TRY(upload(p, &pwt, transposed(w, N, K), st));
-        p->train.ode_w[l] = pw;
-        p->train.ode_w_t[l] = pwt;
-      }
-      TRY(wt.get(pre + ".bias", N, bias));
-      TRY(upload(p, &p->ode_b[l], bias, st));
-    }
-  }
+  // ---- Pose_net: fusion, regressor, ODEFunc (column-sharded), RNN stack
+  TRY(load_pose_net(p, wt, st));
   // ---- Neural-CDE: initial layer, CDEFunc (reference PoseCDE.py:59-66, ODEFunc.py:52-58); reduction_net is unused
   if (cfg->model_type == ODEVIO_MODEL_CDE) {
     const int Hc = cfg->cde_hidden_dim, C = Hc + 1, nh = cfg->cde_fn_num_layers;
@@ -635,60 +710,6 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
         HIPCHK(hipStreamSynchronize(st));
         p->cde.w_last16 = d16;
       }
-    }
-  }
-  // ---- RNN stack: virtual columns over K = [input | hidden]
-  if (cfg->model_type != ODEVIO_MODEL_CDE) {
-    const int L = cfg->rnn_num_layers;
-    const bool gru = cfg->rnn_type == ODEVIO_RNN_GRU;
-    const int gates = gru ? 3 : 1;
-    const int V = gru ? 4 : 1;
-    p->rnn_vcols = V;
-    const int NCF = F / INTEG_MEMBERS;
-    std::vector<float> wih, whh, bih, bhh;
-    for (int l = 0; l < L; ++l) {
-      const std::string s = std::to_string(l);
-      TRY(wt.get("Pose_net.rnn.weight_ih_l" + s, (int64_t)gates * F * F, wih));
-      TRY(wt.get("Pose_net.rnn.weight_hh_l" + s, (int64_t)gates * F * F, whh));
-      TRY(wt.get("Pose_net.rnn.bias_ih_l" + s, (int64_t)gates * F, bih));
-      TRY(wt.get("Pose_net.rnn.bias_hh_l" + s, (int64_t)gates * F, bhh));
-      {   // plain copies for the backward (train.hip): [gates*F][F] and the transposes [F][gates*F]
-        float *a = nullptr, *at = nullptr, *b2 = nullptr, *bt = nullptr, *c = nullptr, *d = nullptr;
-        TRY(upload(p, &a, wih, st));
-        TRY(upload(p, &at, transposed(wih, gates * F, F), st));
-        TRY(upload(p, &b2, whh, st));
-        TRY(upload(p, &bt, transposed(whh, gates * F, F), st));
-        TRY(upload(p, &c, bih, st));
-        TRY(upload(p, &d, bhh, st));
-        p->train.rnn_wih[l] = a; p->train.rnn_wih_t[l] = at; p->train.rnn_whh[l] = b2; p->train.rnn_whh_t[l] = bt;
-        p->train.rnn_bih[l] = c; p->train.rnn_bhh[l] = d;
-      }
-      // virtual matrix [V*F][2F], row order: member-major, then v, then local unit
-      std::vector<float> vm((size_t)V * F * 2 * F, 0.f), vb((size_t)V * F, 0.f);
-      for (int m = 0; m < INTEG_MEMBERS; ++m)
-        for (int v = 0; v < V; ++v)
-          for (int ul = 0; ul < NCF; ++ul) {
-            const int u = m * NCF + ul;
-            float* dst = &vm[((size_t)(m * V + v) * NCF + ul) * 2 * F];
-            if (!gru) {
-              memcpy(dst, &wih[(size_t)u * F], F * sizeof(float));
-              memcpy(dst + F, &whh[(size_t)u * F], F * sizeof(float));
-              vb[u] = bih[u] + bhh[u];
-            } else if (v < 2) {  // r, z
-              memcpy(dst, &wih[((size_t)v * F + u) * F], F * sizeof(float));
-              memcpy(dst + F, &whh[((size_t)v * F + u) * F], F * sizeof(float));
-              vb[(size_t)v * F + u] = bih[(size_t)v * F + u] + bhh[(size_t)v * F + u];
-            } else if (v == 2) {  // n, input part
-              memcpy(dst, &wih[((size_t)2 * F + u) * F], F * sizeof(float));
-              vb[(size_t)2 * F + u] = bih[(size_t)2 * F + u];
-            } else {  // n, hidden part
-              memcpy(dst + F, &whh[((size_t)2 * F + u) * F], F * sizeof(float));
-              vb[(size_t)3 * F + u] = bhh[(size_t)2 * F + u];
-            }
-          }
-      shard_columns(vm, V * F, {F, F}, t);
-      TRY(upload(p, &p->rnn_w[l], t, st));
-      TRY(upload(p, &p->rnn_b[l], vb, st));
     }
   }
   // ---- exchange buffers + status
@@ -1610,6 +1631,72 @@ extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const floa
   if ((rc = ensure(p->train_ws, train_workspace_floats(m, B, P)))) return rc;
   rc = train_ode_rnn_bwd(m, p->train_ws.p, fused, ts, hc_in, B, P, grad_poses, grad_hT, grad_fused, grad_hc, g, st);
   if (rc) return fail(rc, "odevio_ode_rnn_bwd: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, int32_t n_weights, void* stream) {
+  ARGCHK(p && weights && n_weights > 0, "odevio_plan_update: bad argument");
+  if (p->cfg.model_type == ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_plan_update: ode-rnn / rnn plans only");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  HIPCHK(hipStreamSynchronize(st));   // the kernels of earlier calls still read the buffers that are rewritten below
+  WeightTable wt;
+  wt.st = st;
+  for (int i = 0; i < n_weights; ++i)
+    if (weights[i].name) wt.m[weights[i].name] = {weights[i].data, weights[i].numel};
+  return load_pose_net(p, wt, st);
+}
+
+extern "C" int odevio_fuse_bwd(odevio_plan* p, const float* fv, const float* fi, int32_t P, const float* grad_fused, float* grad_fv,
+                               float* grad_fi, const odevio_tensor* grads, int32_t n_grads, void* stream) {
+  ARGCHK(p && fv && fi && grad_fused && P > 0 && n_grads >= 0 && (grads || n_grads == 0), "odevio_fuse_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  const int F = p->F;
+  const bool soft = p->cfg.fuse_method == ODEVIO_FUSE_SOFT;
+  float *gW = nullptr, *gb = nullptr;
+  for (int i = 0; i < n_grads; ++i) {
+    if (!grads[i].name || !grads[i].data) return fail(ODEVIO_ERR_BAD_ARG, "odevio_fuse_bwd: gradient %d has no name / pointer", i);
+    const std::string nm = grads[i].name;
+    int64_t want = -1;
+    if (soft && nm == "Pose_net.fuse.net.0.weight") { gW = (float*)grads[i].data; want = (int64_t)F * F; }
+    else if (soft && nm == "Pose_net.fuse.net.0.bias") { gb = (float*)grads[i].data; want = F; }
+    if (want < 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_fuse_bwd: '%s' is not a parameter of this fusion module", nm.c_str());
+    if (want != grads[i].numel) return fail(ODEVIO_ERR_BAD_ARG, "odevio_fuse_bwd: gradient '%s' has the wrong size", nm.c_str());
+  }
+  int rc;
+  if (soft && (rc = ensure(p->train_aux, train_fuse_workspace_floats(P, F)))) return rc;
+  rc = train_fuse_bwd(soft ? 1 : 0, p->fuse_w, p->fuse_w_t, p->fuse_b, p->train_aux.p, fv, p->cfg.v_f_len, fi, p->cfg.i_f_len, P, grad_fused,
+                      grad_fv, grad_fi, gW, gb, st);
+  if (rc) return fail(rc, "odevio_fuse_bwd: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+extern "C" int odevio_grad_clip(odevio_plan* p, const odevio_tensor* grads, int32_t n_grads, float max_norm, float* norm_coef,
+                                void* stream) {
+  ARGCHK(p && grads && n_grads > 0 && norm_coef && max_norm > 0.f, "odevio_grad_clip: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<const float*> ptr(n_grads);
+  std::vector<size_t> num(n_grads);
+  for (int i = 0; i < n_grads; ++i) {
+    if (!grads[i].data || grads[i].numel <= 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_grad_clip: gradient %d is empty", i);
+    ptr[i] = (const float*)grads[i].data;
+    num[i] = (size_t)grads[i].numel;
+  }
+  int rc;
+  if ((rc = ensure(p->train_aux, 2 * train_grad_clip_workspace_doubles(n_grads)))) return rc;   // doubles in a float buffer
+  rc = train_grad_clip(ptr.data(), num.data(), n_grads, max_norm, reinterpret_cast<double*>(p->train_aux.p), norm_coef, st);
+  if (rc) return fail(rc, "odevio_grad_clip: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+extern "C" int odevio_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int32_t step, const float* norm_coef, void* stream) {
+  ARGCHK(param && grad && exp_avg && exp_avg_sq && numel > 0 && step >= 1 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f &&
+             beta2 < 1.f && eps > 0.f && weight_decay >= 0.f,
+         "odevio_adam_step: bad argument");
+  if (train_adam_step(param, grad, exp_avg, exp_avg_sq, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step, norm_coef, (hipStream_t)stream))
+    return fail(ODEVIO_ERR_HIP, "odevio_adam_step: launch failed");
   return 0;
 }
 

@@ -39,3 +39,14 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
                       const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc, const TrainGrads& g,
                       hipStream_t st);
 int train_pose_loss(const float* poses, const float* gts, int M, float* loss3, float* grad, hipStream_t st);
+
+// FusionModule backward; ws: train_fuse_workspace_floats(P, F) floats (soft only).  W [F][F], W_t its transpose.
+size_t train_fuse_workspace_floats(int P, int F);
+int train_fuse_bwd(int soft, const float* W, const float* W_t, const float* bias, float* ws, const float* fv, int nv, const float* fi, int ni,
+                   int P, const float* g_fused, float* g_fv, float* g_fi, float* g_W, float* g_b, hipStream_t st);
+// clip_grad_norm_ over n gradient tensors: out2[0] = total norm, out2[1] = clip coefficient (device)
+size_t train_grad_clip_workspace_doubles(int n);
+int train_grad_clip(const float* const* grads, const size_t* numel, int n, float max_norm, double* partial_ws, float* out2, hipStream_t st);
+// one torch.optim.Adam update of one tensor; clip2 = the device pair written by train_grad_clip (or null)
+int train_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                    const float* clip2, hipStream_t st);

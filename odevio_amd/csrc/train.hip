@@ -483,3 +483,120 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
   if (g.reg_b2) hipLaunchKernelGGL(colsum_kernel, EW_GRID(6), 0, st, dpo, g.reg_b2, (int)MB, 6);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FusionModule backward (FusionModule.py:17-23).  cat: the gradient is split.  soft: fused = c * (c W^T + b) with
+// c = cat(fv, fi):  g_w = g * c;  g_c = g * w + g_w W;  g_W = g_w^T c;  g_b = column sums of g_w.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void cat_rows_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, float* __restrict__ out, size_t rows) {
+  const int F = na + nb;
+  EW_LOOP(i, rows * F) {
+    const size_t r = i / F;
+    const int c = (int)(i - r * F);
+    out[i] = c < na ? a[r * na + c] : b[r * nb + (c - na)];
+  }
+}
+__global__ void split_rows_kernel(const float* __restrict__ in, float* __restrict__ a, int na, float* __restrict__ b, int nb, size_t rows) {
+  const int F = na + nb;
+  EW_LOOP(i, rows * F) {
+    const size_t r = i / F;
+    const int c = (int)(i - r * F);
+    if (c < na) { if (a) a[r * na + c] = in[i]; }
+    else if (b) b[r * nb + (c - na)] = in[i];
+  }
+}
+// gw = g * c (in place over w's partner buffer), gc = g * w
+__global__ void soft_gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ c, const float* __restrict__ w, float* __restrict__ gw,
+                                     float* __restrict__ gc, size_t n) {
+  EW_LOOP(i, n) {
+    const float gi = g[i];
+    gw[i] = gi * c[i];
+    gc[i] = gi * w[i];
+  }
+}
+
+size_t train_fuse_workspace_floats(int P, int F) { return (size_t)4 * P * F; }
+
+int train_fuse_bwd(int soft, const float* W, const float* W_t, const float* bias, float* ws, const float* fv, int nv, const float* fi, int ni,
+                   int P, const float* g_fused, float* g_fv, float* g_fi, float* g_W, float* g_b, hipStream_t st) {
+  const int F = nv + ni;
+  const size_t n = (size_t)P * F;
+  if (!soft) {
+    hipLaunchKernelGGL(split_rows_kernel, EW_GRID(n), 0, st, g_fused, g_fv, nv, g_fi, ni, (size_t)P);
+    return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+  }
+  float *c = ws, *w = ws + n, *gw = ws + 2 * n, *gc = ws + 3 * n;
+  hipLaunchKernelGGL(cat_rows_kernel, EW_GRID(n), 0, st, fv, nv, fi, ni, c, (size_t)P);
+  gemm_nt(st, c, F, W, F, bias, w, F, P, F, F);                       // w = c W^T + b
+  hipLaunchKernelGGL(soft_gate_bwd_kernel, EW_GRID(n), 0, st, g_fused, c, w, gw, gc, n);
+  gemm_nt(st, gw, F, W_t, F, nullptr, gc, F, P, F, F, true);           // gc += gw W   (W_t rows = columns of W)
+  if (g_W) gemm_tn(st, gw, F, c, F, g_W, F, P, F, F);                  // g_W[n][k] = sum_m gw[m][n] c[m][k]
+  if (g_b) hipLaunchKernelGGL(colsum_kernel, EW_GRID(F), 0, st, gw, g_b, P, F);
+  hipLaunchKernelGGL(split_rows_kernel, EW_GRID(n), 0, st, gc, g_fv, nv, g_fi, ni, (size_t)P);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Optimizer step of the reference's training loop (scripts/train_model.py:84-86, utils/utils.py:115-130):
+// clip_grad_norm_(max_norm) over the gradients, then torch.optim.Adam(betas, eps, weight_decay = L2 added to the gradient).
+// The clip coefficient stays on the device: no host synchronisation inside a training step.
+// ---------------------------------------------------------------------------------------------------------------------
+#define NORM_BLOCKS 64
+// partial[t * NORM_BLOCKS + b] = sum of squares of block b's share of tensor t (fixed shares: deterministic)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* __restrict__ partial) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)NORM_BLOCKS * 256) s += (double)g[i] * (double)g[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// out[0] = total L2 norm, out[1] = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const double* __restrict__ partial, int n_partial, float max_norm, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n_partial; ++i) s += partial[i];
+    const float norm = (float)sqrt(s);
+    out[0] = norm;
+    out[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
+  }
+}
+int train_grad_clip(const float* const* grads, const size_t* numel, int n, float max_norm, double* partial_ws, float* out2, hipStream_t st) {
+  for (int t = 0; t < n; ++t)
+    hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, grads[t], numel[t], partial_ws + (size_t)t * NORM_BLOCKS);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, st, partial_ws, n * NORM_BLOCKS, max_norm, out2);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}
+size_t train_grad_clip_workspace_doubles(int n) { return (size_t)n * NORM_BLOCKS; }
+
+// torch.optim.Adam, single tensor, the arithmetic of torch/optim/adam.py (_single_tensor_adam, amsgrad off, maximize off):
+//   g = clip * grad + weight_decay * p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),  bc_k = 1 - beta_k^step
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                            float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2, const float* __restrict__ clip2) {
+  const float clip = clip2 ? clip2[1] : 1.0f;
+  const float step_size = lr / bc1;
+  EW_LOOP(i, n) {
+    const float pi = p[i];
+    float gi = g[i] * clip;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float m0 = m[i];
+    const float mi = fmaf(gi - m0, 1.f - b1, m0);            // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+int train_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                    const float* clip2, hipStream_t st) {
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float sqrt_bc2 = sqrtf(1.f - powf(b2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, EW_GRID(n), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrt_bc2, clip2);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}

@@ -6,9 +6,13 @@ through the solver's own arithmetic.  Here the same chain is two ``torch.autogra
 run in libodevio (``odevio_ode_rnn_fwd`` / ``odevio_ode_rnn_bwd``, ``odevio_pose_loss``); PyTorch only carries the graph.
 
 What ``odevio_ode_rnn_bwd`` covers: fixed-step solvers (rk4, rk4_classic) and adaptive ones (dopri5, tsit5, heun: the
-forward's accepted steps are replayed, their sizes held constant), ``nn.RNN`` and ``nn.GRU``, ``cat`` fusion;
-gradients reach the encoder FEATURES (fv, fi), the carried state ``hc`` and every parameter of ``Pose_net``
-(ODEFunc, RNN, regressor).  The encoders' own backward is not built yet.
+forward's accepted steps are replayed, their sizes held constant), ``nn.RNN`` and ``nn.GRU``; ``odevio_fuse_bwd`` covers
+``cat`` and ``soft`` fusion.  Gradients reach the encoder FEATURES (fv, fi), the carried state ``hc`` and every parameter
+of ``Pose_net`` (fusion, ODEFunc, RNN, regressor) - exactly the parameters the reference's optimizer holds
+(utils/utils.py:115-119: ``Pose_net.get_other_params()`` + ``get_regressor_params()``; the encoders are not in it).
+``PoseNetTrainer`` is that optimizer step on the device: ``clip_grad_norm_`` + ``torch.optim.Adam`` as kernels
+(``odevio_grad_clip``, ``odevio_adam_step``) and ``odevio_plan_update`` to put the new parameters in front of the forward
+kernels.  The encoders' own backward is not built.
 """
 import ctypes
 
@@ -27,6 +31,44 @@ def pose_param_names(opt):
         names += [f"Pose_net.rnn.{w}_l{k}" for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
     names += [f"Pose_net.regressor.{i}.{w}" for i in (0, 2) for w in ("weight", "bias")]
     return names
+
+
+def fuse_param_names(opt):
+    """Parameters of ``Pose_net.fuse`` (FusionModule.py:11-14): a Linear for ``soft`` (and ``hard``), none for ``cat``."""
+    return ["Pose_net.fuse.net.0.weight", "Pose_net.fuse.net.0.bias"] if opt.fuse_method in ("soft", "hard") else []
+
+
+def _tensor_array(names, tensors):
+    arr = (_lib.OdevioTensor * len(tensors))()
+    for i, (n, t) in enumerate(zip(names, tensors)):
+        arr[i].name, arr[i].data, arr[i].numel = n.encode(), t.data_ptr(), t.numel()
+    return arr
+
+
+class _FuseFunction(torch.autograd.Function):
+    """(fv [B,P,v], fi [B,P,i], *fusion parameters) -> fused [B,P,v+i]  (FusionModule.forward, cat / soft)."""
+
+    @staticmethod
+    def forward(ctx, model, names, fv, fi, *params):
+        fv, fi = fv.detach().contiguous().float(), fi.detach().contiguous().float()
+        fused = model.fuse(fv, fi)
+        ctx.model, ctx.names = model, names
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(fv, fi)
+        return fused
+
+    @staticmethod
+    def backward(ctx, g_fused):
+        model = ctx.model
+        fv, fi = ctx.saved_tensors
+        g_fused = g_fused.contiguous().float()
+        g_fv, g_fi = torch.empty_like(fv), torch.empty_like(fi)
+        grads = [torch.empty(s, device=fv.device, dtype=torch.float32) for s in ctx.param_shapes]
+        arr = _tensor_array(ctx.names, grads)
+        model._ensure_plan()
+        _lib.check(model._lib.odevio_fuse_bwd(model._plan, fv.data_ptr(), fi.data_ptr(), fv.shape[0] * fv.shape[1], g_fused.data_ptr(),
+                                              g_fv.data_ptr(), g_fi.data_ptr(), arr, len(grads), model._stream()))
+        return (None, None, g_fv, g_fi, *grads)
 
 
 class _OdeRnnFunction(torch.autograd.Function):
@@ -106,11 +148,86 @@ def pose_net(model, fv, fi, timestamps, hc=None):
     opt = model.opt
     if opt.model_type not in ("ode-rnn", "rnn"):
         raise ValueError("odevio_amd.train.pose_net: model_type must be ode-rnn or rnn")
-    if opt.fuse_method != "cat":
-        raise ValueError("odevio_amd.train.pose_net: only fuse_method 'cat' has a backward so far")
+    if opt.fuse_method not in ("cat", "soft"):
+        raise ValueError("odevio_amd.train.pose_net: fuse_method 'hard' (straight-through Gumbel mask) has no backward here")
     model._ensure_plan()
     names = pose_param_names(opt)
     params = dict(model.named_parameters())
     plist = [params[n] for n in names]
-    fused = torch.cat((fv, fi), dim=-1)          # plumbing: autograd splits the feature gradient back into fv / fi
+    fnames = fuse_param_names(opt)
+    fused = _FuseFunction.apply(model, fnames, fv, fi, *[params[n] for n in fnames])
     return _OdeRnnFunction.apply(model, names, fused, timestamps, hc, *plist)
+
+
+class PoseNetTrainer:
+    """The reference's optimizer step for ``Pose_net`` on the device (scripts/train_model.py:48-95, utils/utils.py:115-130).
+
+    The reference builds ``torch.optim.Adam(betas=(0.9, 0.999), eps=1e-8, weight_decay=args.weight_decay)`` over
+    ``Pose_net``'s parameters only, and per batch runs forward -> ``100 * MSE(angles) + MSE(translations)`` ->
+    ``backward`` -> ``clip_grad_norm_(max_norm=args.gradient_clip)`` -> ``optimizer.step()`` -> ``zero_grad()``.  Here every
+    one of those stages is a libodevio call; PyTorch carries the graph between them.  ``step`` takes the encoder FEATURES
+    (``model.image_encoder`` / ``model.imu_encoder`` outputs, eval-mode BatchNorm - the encoders' train-mode forward and
+    their backward are not built, and their parameters are not the optimizer's).
+    """
+
+    def __init__(self, model, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, gradient_clip=None):
+        opt = model.opt
+        if opt.model_type not in ("ode-rnn", "rnn"):
+            raise ValueError("PoseNetTrainer: model_type must be ode-rnn or rnn")
+        self.model = model
+        self.lr = float(opt.lr_warmup if lr is None else lr)                       # the reference sets lr per epoch: assign .lr
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        self.weight_decay = float(opt.weight_decay if weight_decay is None else weight_decay)
+        self.gradient_clip = float(opt.gradient_clip if gradient_clip is None else gradient_clip)
+        self.names = fuse_param_names(opt) + pose_param_names(opt)
+        params = dict(model.named_parameters())
+        self.params = [params[n] for n in self.names]
+        for p in self.params:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise RuntimeError("PoseNetTrainer: parameters must be contiguous fp32 tensors on the GPU (model.cuda())")
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.norm_coef = torch.zeros(2, device=self.params[0].device, dtype=torch.float32)   # {total grad norm, clip factor}
+        self.steps = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def apply_gradients(self):
+        """clip_grad_norm_ + Adam on the gradients in ``param.grad`` + the plan's copies refreshed; no host synchronisation
+        except the one inside ``odevio_plan_update``."""
+        model = self.model
+        lib = model._lib
+        grads = []
+        for n, p in zip(self.names, self.params):
+            if p.grad is None:
+                raise RuntimeError(f"PoseNetTrainer: no gradient for {n}")
+            grads.append(p.grad.contiguous().float())
+        stream = model._stream()
+        model._ensure_plan()
+        _lib.check(lib.odevio_grad_clip(model._plan, _tensor_array(self.names, grads), len(grads), self.gradient_clip,
+                                        self.norm_coef.data_ptr(), stream))
+        self.steps += 1
+        for p, g, m, v in zip(self.params, grads, self.exp_avg, self.exp_avg_sq):
+            _lib.check(lib.odevio_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr, self.betas[0],
+                                            self.betas[1], self.eps, self.weight_decay, self.steps, self.norm_coef.data_ptr(), stream))
+        # the kernels read their own layouts of these parameters (column shards, transposes): refresh them in place
+        _lib.check(lib.odevio_plan_update(model._plan, _tensor_array(self.names, [p.detach() for p in self.params]), len(self.params), stream))
+        model._plan_sig = model._signature()
+
+    def step(self, fv, fi, timestamps, gts, hc=None):
+        """One training step on a batch of features; returns (loss, poses, h_T) - ``loss`` a device scalar
+        (``float(loss)`` synchronises, like the reference's ``pose_loss.item()``)."""
+        self.zero_grad()
+        poses, h_T = pose_net(self.model, fv, fi, timestamps, hc)
+        loss = pose_loss(poses, gts)
+        loss.backward()
+        self.apply_gradients()
+        self.zero_grad()
+        return loss.detach(), poses.detach(), h_T.detach()
+
+    @property
+    def grad_norm(self):
+        """Total gradient norm of the last step (device scalar)."""
+        return self.norm_coef[0]

@@ -42,6 +42,8 @@ def _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names, dtype=torch.float64):
     dict(model_type="rnn"),
     dict(ode_solver="rk4", ode_rnn_type="gru"),
     dict(model_type="rnn", ode_rnn_type="gru", rnn_num_layers=3),
+    dict(ode_solver="rk4", fuse_method="soft"),                       # FusionModule "soft": its Linear is a Pose_net parameter
+    dict(model_type="rnn", fuse_method="soft", rnn_num_layers=1),
 ])
 @pytest.mark.parametrize("with_hc", [False, True])
 def test_ode_rnn_backward_matches_autograd_through_the_oracle(cfg, with_hc):
@@ -53,7 +55,7 @@ def test_ode_rnn_backward_matches_autograd_through_the_oracle(cfg, with_hc):
     ts = synth.timestamps(B, P + 1, drop=0.3, seed=3, absolute=with_hc)
     hc = torch.randn(L, B, F, generator=g) * 0.3 if with_hc else None
     gts = torch.randn(B, P, 6, generator=g) * torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
-    names = train.pose_param_names(opt)
+    names = train.fuse_param_names(opt) + train.pose_param_names(opt)
     ref = _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names)
 
     fv_d, fi_d = fv.cuda().requires_grad_(True), fi.cuda().requires_grad_(True)
@@ -118,8 +120,8 @@ def test_backward_refuses_what_is_not_built():
     with pytest.raises(ValueError, match="euler"):
         poses.sum().backward()
 
-    with pytest.raises(ValueError):
-        train.pose_net(make_model(default_opt(img_h=64, img_w=128, fuse_method="soft"), seed=1)[0], fv, fi, synth.timestamps(2, 4).cuda())
+    with pytest.raises(ValueError, match="hard"):
+        train.pose_net(make_model(default_opt(img_h=64, img_w=128, fuse_method="hard"), seed=1)[0], fv, fi, synth.timestamps(2, 4).cuda())
 
 
 def test_pose_loss_matches_the_reference_formula():
@@ -133,3 +135,84 @@ def test_pose_loss_matches_the_reference_formula():
     ref.backward()
     assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
     assert oc.rel_err(pd.grad, p64.grad) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the optimizer step of the reference's training loop (scripts/train_model.py:76-86, utils/utils.py:115-130)
+# ---------------------------------------------------------------------------------------------------------------------
+def _torch_reference_training(sd, opt, names, batches, lr, weight_decay, clip, eps):
+    """The reference's loop on the oracle: torch autograd (fp32, like the reference), clip_grad_norm_, torch.optim.Adam over
+    Pose_net's parameters."""
+    leaves = {k: v.clone().float() for k, v in sd.items() if v.is_floating_point()}
+    params = [leaves[n].requires_grad_(True) for n in names]
+    optim = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=weight_decay)
+    losses, norms = [], []
+    for fv, fi, ts, gts in batches:
+        optim.zero_grad()
+        poses, _ = oc.pose_ode_rnn(leaves, fv, fi, ts, None, opt, with_ode=opt.model_type == "ode-rnn", detach_controller=True)
+        loss = 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3]) + torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:])
+        loss.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(params, max_norm=clip)))
+        optim.step()
+        losses.append(float(loss))
+    return {n: p.detach() for n, p in zip(names, params)}, losses, norms
+
+
+@pytest.mark.parametrize("cfg,clip", [
+    (dict(ode_solver="rk4"), 5.0),                                  # the reference's defaults: clipping rarely active
+    (dict(ode_solver="rk4", fuse_method="soft"), 0.05),            # clipping active in every step
+    (dict(model_type="rnn", ode_rnn_type="gru"), 5.0),
+])
+def test_pose_net_trainer_follows_torch_adam_on_the_oracle(cfg, clip):
+    opt = default_opt(img_h=64, img_w=128, **cfg)
+    model, sd = make_model(opt, seed=81)
+    B, P = 3, 4
+    g = torch.Generator().manual_seed(9)
+    scale = torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    batches = [(torch.randn(B, P, 512, generator=g), torch.randn(B, P, 256, generator=g), synth.timestamps(B, P + 1, drop=0.2, seed=20 + k),
+                torch.randn(B, P, 6, generator=g) * scale) for k in range(4)]
+    lr, wd, eps = 1e-4, 5e-5, 1e-8
+    trainer = train.PoseNetTrainer(model, lr=lr, weight_decay=wd, gradient_clip=clip, eps=eps)
+    ref_params, ref_losses, ref_norms = _torch_reference_training(sd, opt, trainer.names, batches, lr, wd, clip, eps)
+    before = {n: p.detach().clone() for n, p in zip(trainer.names, trainer.params)}
+    losses, norms = [], []
+    for fv, fi, ts, gts in batches:
+        loss, poses, _ = trainer.step(fv.cuda(), fi.cuda(), ts.cuda(), gts.cuda())
+        losses.append(float(loss))
+        norms.append(float(trainer.grad_norm))
+    model.check()
+    for a, b in zip(losses, ref_losses):           # the loss of step k sees the parameters of steps < k: the updates took effect
+        assert abs(a - b) <= 2e-4 * abs(b), (losses, ref_losses)
+    for a, b in zip(norms, ref_norms):
+        assert abs(a - b) <= 2e-3 * b, (norms, ref_norms)
+    if clip < 1.0:
+        assert min(ref_norms) > clip               # the case is meant to clip
+    # Adam's update is lr * m_hat / (sqrt(v_hat) + eps): +-lr-sized whatever the gradient's size, so an element whose gradient
+    # is ~0 can differ by a fraction of lr between two fp32 implementations; everything else must agree closely
+    moved = 0.0
+    for n, p in zip(trainer.names, trainer.params):
+        d = (p.detach().cpu() - ref_params[n]).abs()
+        moved = max(moved, float((p.detach().cpu() - before[n].cpu()).abs().max()))
+        assert float(d.max()) <= 1.0 * lr * len(batches), f"{n}: max diff {float(d.max()):.2e}"
+        assert float((d > 0.02 * lr).float().mean()) < 2e-3, f"{n}: {float((d > 0.02 * lr).float().mean()):.2e} of the elements differ by more than 2 % of lr"
+    assert moved > 0.5 * lr                        # parameters did move
+    # and the forward kernels see the new parameters: a plain forward equals the oracle on the reference-trained weights
+    fv, fi, ts, _ = batches[0]
+    new_sd = dict(sd)
+    new_sd.update(ref_params)
+    poses_ref, _ = oc.pose_ode_rnn(new_sd, fv, fi, ts, None, opt, with_ode=opt.model_type == "ode-rnn")
+    poses_now, _ = model.pose_net(fv.cuda(), fi.cuda(), ts.cuda())
+    assert oc.rel_err(poses_now, poses_ref) < 5e-4
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    model, _ = make_model(opt, seed=82)
+    g = torch.Generator().manual_seed(10)
+    fv, fi = torch.randn(4, 5, 512, generator=g).cuda(), torch.randn(4, 5, 256, generator=g).cuda()
+    ts = synth.timestamps(4, 6, seed=30).cuda()
+    gts = (torch.randn(4, 5, 6, generator=g) * torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])).cuda()
+    trainer = train.PoseNetTrainer(model, lr=1e-3)
+    losses = [float(trainer.step(fv, fi, ts, gts)[0]) for _ in range(12)]
+    model.check()
+    assert losses[-1] < 0.7 * losses[0], losses
