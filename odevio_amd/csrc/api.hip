@@ -1634,17 +1634,91 @@ extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const floa
   return 0;
 }
 
+// odevio_plan_update: the index maps of load_pose_net as device kernels, from the caller's device tensors straight into the
+// plan's buffers on the caller's stream (ordered behind the kernels that still read the old values; no host round trip).
 extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, int32_t n_weights, void* stream) {
   ARGCHK(p && weights && n_weights > 0, "odevio_plan_update: bad argument");
   if (p->cfg.model_type == ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_plan_update: ode-rnn / rnn plans only");
   hipStream_t st = (hipStream_t)stream;
   POLL(p, st);
-  HIPCHK(hipStreamSynchronize(st));   // the kernels of earlier calls still read the buffers that are rewritten below
-  WeightTable wt;
-  wt.st = st;
+  std::map<std::string, std::pair<const float*, int64_t>> m;
   for (int i = 0; i < n_weights; ++i)
-    if (weights[i].name) wt.m[weights[i].name] = {weights[i].data, weights[i].numel};
-  return load_pose_net(p, wt, st);
+    if (weights[i].name && weights[i].data) m[weights[i].name] = {(const float*)weights[i].data, weights[i].numel};
+  const int F = p->F;
+  int rc = 0;
+  auto src = [&](const std::string& name, int64_t numel) -> const float* {
+    auto it = m.find(name);
+    if (it == m.end()) { rc = fail(ODEVIO_ERR_MISSING_WEIGHT, "odevio_plan_update: weight '%s' not provided", name.c_str()); return nullptr; }
+    if (it->second.second != numel) { rc = fail(ODEVIO_ERR_BAD_ARG, "odevio_plan_update: weight '%s' has the wrong size", name.c_str()); return nullptr; }
+    return it->second.first;
+  };
+  auto copy = [&](float* dst, const float* s, size_t n) {
+    if (!rc && hipMemcpyAsync(dst, s, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = fail(ODEVIO_ERR_HIP, "odevio_plan_update: copy failed");
+  };
+  // first pass: every tensor present with the right size (nothing is written before that is known)
+  std::vector<std::pair<std::string, int64_t>> need;
+  if (p->cfg.fuse_method == ODEVIO_FUSE_SOFT) { need.push_back({"Pose_net.fuse.net.0.weight", (int64_t)F * F}); need.push_back({"Pose_net.fuse.net.0.bias", F}); }
+  need.push_back({"Pose_net.regressor.0.weight", (int64_t)128 * F}); need.push_back({"Pose_net.regressor.0.bias", 128});
+  need.push_back({"Pose_net.regressor.2.weight", 6 * 128}); need.push_back({"Pose_net.regressor.2.bias", 6});
+  if (p->cfg.model_type == ODEVIO_MODEL_ODE_RNN)
+    for (int l = 0; l < p->nlin; ++l) {
+      const std::string pre = "Pose_net.ode_func.net." + std::to_string(2 * l);
+      need.push_back({pre + ".weight", (int64_t)p->dims[l + 1] * p->dims[l]});
+      need.push_back({pre + ".bias", p->dims[l + 1]});
+    }
+  const bool gru = p->cfg.rnn_type == ODEVIO_RNN_GRU;
+  const int64_t GF = (int64_t)(gru ? 3 : 1) * F;
+  for (int l = 0; l < p->cfg.rnn_num_layers; ++l) {
+    const std::string s = std::to_string(l);
+    need.push_back({"Pose_net.rnn.weight_ih_l" + s, GF * F}); need.push_back({"Pose_net.rnn.weight_hh_l" + s, GF * F});
+    need.push_back({"Pose_net.rnn.bias_ih_l" + s, GF}); need.push_back({"Pose_net.rnn.bias_hh_l" + s, GF});
+  }
+  for (const auto& nd : need) {
+    (void)src(nd.first, nd.second);
+    if (rc) return rc;
+  }
+  // second pass: the layouts of load_pose_net
+  if (p->cfg.fuse_method == ODEVIO_FUSE_SOFT) {
+    const float* w = src("Pose_net.fuse.net.0.weight", (int64_t)F * F);
+    copy(p->fuse_w, w, (size_t)F * F);
+    relayout_transpose(w, p->fuse_w_t, F, F, st);
+    copy(p->fuse_b, src("Pose_net.fuse.net.0.bias", F), F);
+  }
+  {
+    const float* w = src("Pose_net.regressor.0.weight", (int64_t)128 * F);
+    copy(p->reg_w0, w, (size_t)128 * F);
+    relayout_transpose(w, const_cast<float*>(p->train.reg_w0_t), 128, F, st);
+    copy(p->reg_b0, src("Pose_net.regressor.0.bias", 128), 128);
+    copy(p->reg_w2, src("Pose_net.regressor.2.weight", 6 * 128), 6 * 128);
+    copy(p->reg_b2, src("Pose_net.regressor.2.bias", 6), 6);
+  }
+  if (p->cfg.model_type == ODEVIO_MODEL_ODE_RNN)
+    for (int l = 0; l < p->nlin; ++l) {
+      const std::string pre = "Pose_net.ode_func.net." + std::to_string(2 * l);
+      const int N = p->dims[l + 1], K = p->dims[l];
+      const float* w = src(pre + ".weight", (int64_t)N * K);
+      relayout_shard(w, p->ode_w[l], N, K, INTEG_MEMBERS, st);
+      copy(const_cast<float*>(p->train.ode_w[l]), w, (size_t)N * K);
+      relayout_transpose(w, const_cast<float*>(p->train.ode_w_t[l]), N, K, st);
+      copy(p->ode_b[l], src(pre + ".bias", N), N);
+    }
+  for (int l = 0; l < p->cfg.rnn_num_layers; ++l) {
+    const std::string s = std::to_string(l);
+    const float* wih = src("Pose_net.rnn.weight_ih_l" + s, GF * F);
+    const float* whh = src("Pose_net.rnn.weight_hh_l" + s, GF * F);
+    const float* bih = src("Pose_net.rnn.bias_ih_l" + s, GF);
+    const float* bhh = src("Pose_net.rnn.bias_hh_l" + s, GF);
+    copy(const_cast<float*>(p->train.rnn_wih[l]), wih, (size_t)GF * F);
+    copy(const_cast<float*>(p->train.rnn_whh[l]), whh, (size_t)GF * F);
+    copy(const_cast<float*>(p->train.rnn_bih[l]), bih, GF);
+    copy(const_cast<float*>(p->train.rnn_bhh[l]), bhh, GF);
+    relayout_transpose(wih, const_cast<float*>(p->train.rnn_wih_t[l]), (int)GF, F, st);
+    relayout_transpose(whh, const_cast<float*>(p->train.rnn_whh_t[l]), (int)GF, F, st);
+    relayout_rnn(wih, whh, bih, bhh, p->rnn_w[l], p->rnn_b[l], F, gru ? 1 : 0, INTEG_MEMBERS, st);
+  }
+  if (rc) return rc;
+  if (hipGetLastError() != hipSuccess) return fail(ODEVIO_ERR_HIP, "odevio_plan_update: a re-layout kernel failed to launch");
+  return 0;
 }
 
 extern "C" int odevio_fuse_bwd(odevio_plan* p, const float* fv, const float* fi, int32_t P, const float* grad_fused, float* grad_fv,

@@ -50,3 +50,8 @@ int train_grad_clip(const float* const* grads, const size_t* numel, int n, float
 // one torch.optim.Adam update of one tensor; clip2 = the device pair written by train_grad_clip (or null)
 int train_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
                     const float* clip2, hipStream_t st);
+// parameter re-layout on the device (the index maps of odevio_plan_create's host code)
+void relayout_transpose(const float* src, float* dst, int N, int K, hipStream_t st);
+void relayout_shard(const float* W, float* out, int N, int K, int members, hipStream_t st);
+void relayout_rnn(const float* wih, const float* whh, const float* bih, const float* bhh, float* out_w, float* out_b, int F, int gru, int members,
+                  hipStream_t st);

@@ -600,3 +600,74 @@ int train_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
   hipLaunchKernelGGL(adam_kernel, EW_GRID(n), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrt_bc2, clip2);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Parameter re-layout on the device (odevio_plan_update): the same index maps as the host code of odevio_plan_create
+// (api.hip: transposed(), shard_columns(), the RNN's virtual matrix), so that an optimizer step needs no host round trip.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K) {   // dst[k][n] = src[n][k]
+  EW_LOOP(i, (size_t)N * K) {
+    const int k = (int)(i / N), n = (int)(i - (size_t)k * N);
+    dst[i] = src[(size_t)n * K + k];
+  }
+}
+// [N][K] row-major -> member-major column shards with K padded to 256-wide chunks: member m, chunk j, column c, lane, 4
+__global__ void shard_kernel(const float* __restrict__ W, float* __restrict__ out, int N, int K, int members) {
+  const int NC = N / members, Kp = (K + 255) & ~255;
+  EW_LOOP(i, (size_t)N * Kp) {
+    const size_t per = (size_t)NC * Kp;
+    const int m = (int)(i / per);
+    const size_t r = i - (size_t)m * per;
+    const int j = (int)(r / ((size_t)NC * 256));
+    const int r2 = (int)(r - (size_t)j * NC * 256);
+    const int col = r2 >> 8, k = j * 256 + (r2 & 255);
+    out[i] = k < K ? W[(size_t)(m * NC + col) * K + k] : 0.f;
+  }
+}
+// the RNN stack's virtual columns over K = [input | hidden] (tanh RNN: one per unit; GRU: r, z, n-input, n-hidden), sharded
+__global__ void rnn_shard_kernel(const float* __restrict__ wih, const float* __restrict__ whh, float* __restrict__ out, int F, int gru,
+                                 int members) {
+  const int V = gru ? 4 : 1, NCF = F / members, NC = V * NCF, Fp = (F + 255) & ~255, Kp = 2 * Fp;
+  EW_LOOP(i, (size_t)V * F * Kp) {
+    const size_t per = (size_t)NC * Kp;
+    const int m = (int)(i / per);
+    const size_t r = i - (size_t)m * per;
+    const int j = (int)(r / ((size_t)NC * 256));
+    const int r2 = (int)(r - (size_t)j * NC * 256);
+    const int col = r2 >> 8, kp = j * 256 + (r2 & 255);
+    const int seg = kp / Fp, k = kp - seg * Fp;
+    const int v = col / NCF, u = m * NCF + (col - v * NCF);
+    float val = 0.f;
+    if (k < F) {
+      if (!gru) val = seg == 0 ? wih[(size_t)u * F + k] : whh[(size_t)u * F + k];
+      else if (v < 2) val = seg == 0 ? wih[((size_t)v * F + u) * F + k] : whh[((size_t)v * F + u) * F + k];
+      else if (v == 2) val = seg == 0 ? wih[((size_t)2 * F + u) * F + k] : 0.f;
+      else val = seg == 0 ? 0.f : whh[((size_t)2 * F + u) * F + k];
+    }
+    out[i] = val;
+  }
+}
+__global__ void rnn_bias_kernel(const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ vb, int F, int gru) {
+  const int V = gru ? 4 : 1;
+  EW_LOOP(i, (size_t)V * F) {
+    const int v = (int)(i / F), u = (int)(i - (size_t)v * F);
+    float x;
+    if (!gru) x = bih[u] + bhh[u];
+    else if (v < 2) x = bih[(size_t)v * F + u] + bhh[(size_t)v * F + u];
+    else if (v == 2) x = bih[(size_t)2 * F + u];
+    else x = bhh[(size_t)2 * F + u];
+    vb[i] = x;
+  }
+}
+void relayout_transpose(const float* src, float* dst, int N, int K, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, EW_GRID((size_t)N * K), 0, st, src, dst, N, K);
+}
+void relayout_shard(const float* W, float* out, int N, int K, int members, hipStream_t st) {
+  hipLaunchKernelGGL(shard_kernel, EW_GRID((size_t)N * ((K + 255) & ~255)), 0, st, W, out, N, K, members);
+}
+void relayout_rnn(const float* wih, const float* whh, const float* bih, const float* bhh, float* out_w, float* out_b, int F, int gru, int members,
+                  hipStream_t st) {
+  const int V = gru ? 4 : 1;
+  hipLaunchKernelGGL(rnn_shard_kernel, EW_GRID((size_t)V * F * 2 * ((F + 255) & ~255)), 0, st, wih, whh, out_w, F, gru, members);
+  hipLaunchKernelGGL(rnn_bias_kernel, EW_GRID((size_t)V * F), 0, st, bih, bhh, out_b, F, gru);
+}

@@ -195,8 +195,8 @@ class PoseNetTrainer:
             p.grad = None
 
     def apply_gradients(self):
-        """clip_grad_norm_ + Adam on the gradients in ``param.grad`` + the plan's copies refreshed; no host synchronisation
-        except the one inside ``odevio_plan_update``."""
+        """clip_grad_norm_ + Adam on the gradients in ``param.grad`` + the plan's copies refreshed (device re-layout kernels);
+        nothing here synchronises with the host."""
         model = self.model
         lib = model._lib
         grads = []

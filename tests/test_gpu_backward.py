@@ -203,6 +203,23 @@ def test_pose_net_trainer_follows_torch_adam_on_the_oracle(cfg, clip):
     poses_ref, _ = oc.pose_ode_rnn(new_sd, fv, fi, ts, None, opt, with_ode=opt.model_type == "ode-rnn")
     poses_now, _ = model.pose_net(fv.cuda(), fi.cuda(), ts.cuda())
     assert oc.rel_err(poses_now, poses_ref) < 5e-4
+    # the in-place refresh (device re-layout kernels) leaves the plan exactly as a fresh plan built from the same parameters
+    from odevio_amd import DeepVIO
+    fresh = DeepVIO(opt, seed=0, state_dict={k: v.detach().cpu().clone() for k, v in model.state_dict().items()}).cuda()
+    poses_fresh, hT_fresh = fresh.pose_net(fv.cuda(), fi.cuda(), ts.cuda())
+    assert torch.equal(poses_now, poses_fresh)
+    # ... for the backward's copies (plain and transposed weights) too: identical gradients
+    for mdl in (model, fresh):
+        for p in mdl.parameters():
+            p.grad = None
+    outs = []
+    for mdl in (model, fresh):
+        fvd = fv.cuda().requires_grad_(True)
+        po, _ = train.pose_net(mdl, fvd, fi.cuda(), ts.cuda())
+        train.pose_loss(po, batches[0][3].cuda()).backward()
+        outs.append([fvd.grad] + [dict(mdl.named_parameters())[n].grad for n in trainer.names])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_training_reduces_the_loss_on_a_fixed_batch():

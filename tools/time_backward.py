@@ -39,3 +39,28 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"pose-net training step (fwd + bwd below the encoders), B={B}, {P} intervals, {solver}, {rnn}: {dt * 1e3:.2f} ms")
+
+# the whole optimizer step of the reference's loop (clip_grad_norm_ + Adam + the plan's layouts refreshed): PoseNetTrainer
+trainer = train.PoseNetTrainer(m)
+fvd, fid = fv.detach(), fi.detach()
+for _ in range(3):
+    trainer.step(fvd, fid, ts, gts)
+m.check()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    trainer.step(fvd, fid, ts, gts)
+torch.cuda.synchronize()
+dt2 = (time.perf_counter() - t0) / n
+ta = 0.0
+for _ in range(n):
+    trainer.zero_grad()
+    poses, _ = train.pose_net(m, fvd, fid, ts)
+    train.pose_loss(poses, gts).backward()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    trainer.apply_gradients()
+    torch.cuda.synchronize()
+    ta += time.perf_counter() - t1
+print(f"  of which clip + Adam over {len(trainer.params)} tensors + plan refresh: {ta / n * 1e3:.2f} ms")
+print(f"PoseNetTrainer.step (fwd + bwd + clip + Adam + plan refresh): {dt2 * 1e3:.2f} ms per step")
