@@ -184,6 +184,14 @@ int odevio_pose_loss(const float* poses, const float* gts, int32_t n_rows, float
 int odevio_fuse_bwd(odevio_plan* plan, const float* fv, const float* fi, int32_t P, const float* grad_fused, float* grad_fv,
                     float* grad_fi, const odevio_tensor* grads, int32_t n_grads, void* stream);
 
+/* InertialEncoder backward (reference src/models/Encoder.py:41-74, BatchNorm in eval mode like odevio_imu_encoder_fwd, imu_dropout 0):
+ * imu [B,T,6], grad_fi [B*(T-1)/10, i_f_len] contiguous -> the gradients of the Inertial_net parameters named in `grads`
+ * (encoder_conv.{0,4,8}.weight/bias, encoder_conv.{1,5,9}.weight/bias, proj.weight/bias; device pointers, reference shapes).
+ * In the reference's recipe (--freeze_encoder freezes Image_net only) these gradients enter the step through
+ * clip_grad_norm_(model.parameters()); its optimizer does not hold them (utils/utils.py:116-119). */
+int odevio_imu_encoder_bwd(odevio_plan* plan, const float* imu, int32_t B, int32_t T, const float* grad_fi, const odevio_tensor* grads,
+                           int32_t n_grads, void* stream);
+
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) as the reference calls it before optimizer.step()
  * (scripts/train_model.py:84): the total L2 norm over the n gradient tensors and the factor min(1, max_norm / (norm + 1e-6)),
  * written to the device pair norm_coef = {norm, factor}.  Nothing is scaled here and nothing returns to the host:

@@ -25,7 +25,7 @@ SYMBOLS = [
     "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
     "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func", "odevio_cde_last_ms",
     "odevio_ode_rnn_bwd", "odevio_pose_loss", "odevio_resize_u8", "odevio_resize_table",
-    "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update",
+    "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update", "odevio_imu_encoder_bwd",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
     lib.odevio_grad_clip.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, f32, fp, vp]
     lib.odevio_adam_step.argtypes = [fp, fp, fp, fp, ctypes.c_int64, f32, f32, f32, f32, f32, i32, fp, vp]
     lib.odevio_plan_update.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, vp]
+    lib.odevio_imu_encoder_bwd.argtypes = [vp, fp, i32, i32, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_resize_table.argtypes = [i32, i32, vp, vp, vp, i32]
     lib.odevio_resize_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.odevio_cde_func.argtypes = [vp, fp, fp, i32, i32, i32, fp, vp]

@@ -98,6 +98,7 @@ struct odevio_plan {
   float* head_scale_h = nullptr; // 1 / prescale per output
   int head_k = 0;
   float *imu_w[3] = {}, *imu_s[3] = {}, *imu_h[3] = {};
+  float *imu_wref[3] = {}, *imu_var[3] = {}, *imu_mean[3] = {}, *imu_bias[3] = {};   // backward: reference-layout weights (rows padded to 16), BatchNorm statistics
   float *proj_w = nullptr, *proj_b = nullptr;
   float *fuse_w = nullptr, *fuse_b = nullptr, *fuse_w_t = nullptr;
   float *reg_w0 = nullptr, *reg_b0 = nullptr, *reg_w2 = nullptr, *reg_b2 = nullptr;
@@ -665,6 +666,18 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       TRY(bn_fold(wt, "Inertial_net.encoder_conv." + std::to_string(idx[i] + 1), cout[i], &bias, sc, sh));
       TRY(upload(p, &p->imu_s[i], sc, st));
       TRY(upload(p, &p->imu_h[i], sh, st));
+      {   // for odevio_imu_encoder_bwd: [cout][ldk] with ldk = 3 cin rounded up to 16 (zero pad), the conv bias, the running statistics
+        const int k3 = 3 * cin[i], ldk = (k3 + 15) / 16 * 16;
+        std::vector<float> wr((size_t)cout[i] * ldk, 0.f), mu, var;
+        for (int co = 0; co < cout[i]; ++co) memcpy(&wr[(size_t)co * ldk], &w[(size_t)co * k3], k3 * sizeof(float));
+        TRY(upload(p, &p->imu_wref[i], wr, st));
+        TRY(upload(p, &p->imu_bias[i], bias, st));
+        const std::string bn = "Inertial_net.encoder_conv." + std::to_string(idx[i] + 1);
+        TRY(wt.get(bn + ".running_mean", cout[i], mu));
+        TRY(wt.get(bn + ".running_var", cout[i], var));
+        TRY(upload(p, &p->imu_mean[i], mu, st));
+        TRY(upload(p, &p->imu_var[i], var, st));
+      }
     }
     TRY(wt.get("Inertial_net.proj.weight", (int64_t)cfg->i_f_len * 2816, w));
     TRY(upload(p, &p->proj_w, w, st));
@@ -1743,6 +1756,50 @@ extern "C" int odevio_fuse_bwd(odevio_plan* p, const float* fv, const float* fi,
   rc = train_fuse_bwd(soft ? 1 : 0, p->fuse_w, p->fuse_w_t, p->fuse_b, p->train_aux.p, fv, p->cfg.v_f_len, fi, p->cfg.i_f_len, P, grad_fused,
                       grad_fv, grad_fi, gW, gb, st);
   if (rc) return fail(rc, "odevio_fuse_bwd: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+extern "C" int odevio_imu_encoder_bwd(odevio_plan* p, const float* imu, int32_t B, int32_t T, const float* grad_fi, const odevio_tensor* grads,
+                                      int32_t n_grads, void* stream) {
+  ARGCHK(p && imu && grad_fi && B > 0 && T >= 11 && (T - 1) % 10 == 0 && n_grads >= 0 && (grads || n_grads == 0), "odevio_imu_encoder_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  ImuTrain m{};
+  ImuGrads g{};
+  const int cin[3] = {6, 64, 128}, cout[3] = {64, 128, 256}, idx[3] = {0, 4, 8};
+  for (int i = 0; i < 3; ++i) {
+    m.w[i] = p->imu_wref[i]; m.wt[i] = p->imu_w[i]; m.s[i] = p->imu_s[i]; m.h[i] = p->imu_h[i];
+    m.var[i] = p->imu_var[i]; m.mean[i] = p->imu_mean[i]; m.bias[i] = p->imu_bias[i];
+    m.ldk[i] = (3 * cin[i] + 15) / 16 * 16;
+  }
+  m.eps = 1e-5f;
+  m.proj_w = p->proj_w;
+  m.i_f_len = p->cfg.i_f_len;
+  if (m.i_f_len % 16) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_imu_encoder_bwd: i_f_len must be a multiple of 16");
+  for (int j = 0; j < n_grads; ++j) {
+    if (!grads[j].name || !grads[j].data) return fail(ODEVIO_ERR_BAD_ARG, "odevio_imu_encoder_bwd: gradient %d has no name / pointer", j);
+    const std::string nm = grads[j].name;
+    float* dst = (float*)grads[j].data;
+    int64_t want = -1;
+    for (int i = 0; i < 3 && want < 0; ++i) {
+      const std::string cv = "Inertial_net.encoder_conv." + std::to_string(idx[i]), bn = "Inertial_net.encoder_conv." + std::to_string(idx[i] + 1);
+      if (nm == cv + ".weight") { g.w[i] = dst; want = (int64_t)cout[i] * cin[i] * 3; }
+      else if (nm == cv + ".bias") { g.b[i] = dst; want = cout[i]; }
+      else if (nm == bn + ".weight") { g.gamma[i] = dst; want = cout[i]; }
+      else if (nm == bn + ".bias") { g.beta[i] = dst; want = cout[i]; }
+    }
+    if (want < 0) {
+      if (nm == "Inertial_net.proj.weight") { g.proj_w = dst; want = (int64_t)m.i_f_len * 2816; }
+      else if (nm == "Inertial_net.proj.bias") { g.proj_b = dst; want = m.i_f_len; }
+    }
+    if (want < 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_imu_encoder_bwd: '%s' is not a parameter of Inertial_net", nm.c_str());
+    if (want != grads[j].numel) return fail(ODEVIO_ERR_BAD_ARG, "odevio_imu_encoder_bwd: gradient '%s' has the wrong size", nm.c_str());
+  }
+  const int P = B * ((T - 1) / 10);
+  int rc;
+  if ((rc = ensure(p->train_aux, train_imu_workspace_floats(P)))) return rc;
+  rc = train_imu_bwd(m, p->train_aux.p, imu, B, T, grad_fi, nullptr, g, st);
+  if (rc) return fail(rc, "odevio_imu_encoder_bwd: %s", hipGetErrorString(hipGetLastError()));
   return 0;
 }
 

@@ -55,3 +55,20 @@ void relayout_transpose(const float* src, float* dst, int N, int K, hipStream_t 
 void relayout_shard(const float* W, float* out, int N, int K, int members, hipStream_t st);
 void relayout_rnn(const float* wih, const float* whh, const float* bih, const float* bhh, float* out_w, float* out_b, int F, int gru, int members,
                   hipStream_t st);
+
+// InertialEncoder backward (eval-mode BatchNorm).  Conv weights twice: reference layout [cout][ldk] (rows zero-padded from
+// 3 cin to ldk, a multiple of 16) and the forward kernel's [(ci,k)][cout]; s / h = the folded BatchNorm + conv bias.
+struct ImuTrain {
+  const float *w[3], *wt[3], *s[3], *h[3], *var[3], *mean[3], *bias[3];
+  int ldk[3];
+  float eps;
+  const float* proj_w;   // [i_f_len][2816]
+  int i_f_len;
+};
+struct ImuGrads {       // reference shapes; null = not wanted
+  float *w[3], *b[3], *gamma[3], *beta[3], *proj_w, *proj_b;
+};
+size_t train_imu_workspace_floats(int P);
+// imu [B][T][6], g_fi [B * (T-1)/10][i_f_len] contiguous; g_imu_rows (optional) [(pair, t)][6]: gradient w.r.t. the windowed samples
+int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, const float* g_fi, float* g_imu_rows, const ImuGrads& g,
+                  hipStream_t st);

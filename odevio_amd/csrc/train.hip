@@ -671,3 +671,159 @@ void relayout_rnn(const float* wih, const float* whh, const float* bih, const fl
   hipLaunchKernelGGL(rnn_shard_kernel, EW_GRID((size_t)V * F * 2 * ((F + 255) & ~255)), 0, st, wih, whh, out_w, F, gru, members);
   hipLaunchKernelGGL(rnn_bias_kernel, EW_GRID((size_t)V * F), 0, st, bih, bhh, out_b, F, gru);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// InertialEncoder backward (Encoder.py:41-74; eval-mode BatchNorm like the forward kernel, imu_dropout = 0).
+// Everything is a row matrix over rows = (frame pair, time step): a Conv1d(k3, p1) is X_col [rows][3 cin] x W^T, so the
+// recomputed forward, the weight gradients (D^T X_col) and the input gradients (D W, then col2im) are the skinny GEMMs
+// above; BatchNorm(eval) + conv bias are the folded pair (s, h) of the forward: y = leaky(s c + h), c = the bare convolution.
+//   dz = g_y * leaky'(y);  dS = sum dz c;  dH = sum dz;  D = dz s
+//   g_gamma = (dS + dH (b - mean)) rstd;  g_beta = dH;  g_bias = dH s;  g_W = D^T X_col;  g_Xcol = D W
+// ---------------------------------------------------------------------------------------------------------------------
+#define IMU_T 11
+// x0 [rows][6] from the 100 Hz stream imu [B][T][6]: pair (b, p) covers samples 10p .. 10p+10
+__global__ void imu_window_kernel(const float* __restrict__ imu, float* __restrict__ x0, int B, int T, int pps) {
+  EW_LOOP(i, (size_t)B * pps * IMU_T * 6) {
+    const int c = (int)(i % 6);
+    const size_t r = i / 6;
+    const int t = (int)(r % IMU_T);
+    const size_t pair = r / IMU_T;
+    const int b = (int)(pair / pps), p = (int)(pair - (size_t)b * pps);
+    x0[i] = imu[((size_t)b * T + 10 * p + t) * 6 + c];
+  }
+}
+// X_col[(pair,t)][ci*3 + k] = x[(pair, t + k - 1)][ci] (zero outside 0..10)
+// (row stride ld >= 3 C, a multiple of 16 for the GEMM's k-steps: columns 3 C .. ld - 1 are zero)
+__global__ void im2col3_kernel(const float* __restrict__ x, float* __restrict__ xcol, size_t rows, int C, int ld) {
+  EW_LOOP(i, rows * ld) {
+    const size_t r = i / ld;
+    const int q = (int)(i - r * ld), ci = q / 3, k = q - 3 * ci;
+    const int t = (int)(r % IMU_T) + k - 1;
+    xcol[i] = (q < 3 * C && t >= 0 && t < IMU_T) ? x[(r + k - 1) * C + ci] : 0.f;
+  }
+}
+// g_x[(pair,t')][ci] = sum_k g_xcol[(pair, t' - k + 1)][ci*3 + k]
+__global__ void col2im3_kernel(const float* __restrict__ gcol, float* __restrict__ gx, size_t rows, int C) {
+  EW_LOOP(i, rows * C) {
+    const size_t r = i / C;
+    const int ci = (int)(i - r * C), t = (int)(r % IMU_T);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ts = t - k + 1;
+      if (ts >= 0 && ts < IMU_T) s += gcol[(r - k + 1) * 3 * C + ci * 3 + k];
+    }
+    gx[i] = s;
+  }
+}
+__global__ void bn_leaky_fwd_kernel(const float* __restrict__ c, const float* __restrict__ s, const float* __restrict__ h, float* __restrict__ y,
+                                    size_t rows, int C) {
+  EW_LOOP(i, rows * C) {
+    const int ch = (int)(i % C);
+    const float v = fmaf(c[i], s[ch], h[ch]);
+    y[i] = v > 0.f ? v : 0.1f * v;
+  }
+}
+// dz = g * leaky'(y) -> dzc = dz * c (for dS), D = dz * s (over g in place allowed: outputs are separate buffers)
+__global__ void bn_leaky_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ c, const float* __restrict__ s,
+                                    float* __restrict__ dz, float* __restrict__ dzc, float* __restrict__ D, size_t rows, int C) {
+  EW_LOOP(i, rows * C) {
+    const int ch = (int)(i % C);
+    const float d = g[i] * (y[i] > 0.f ? 1.f : 0.1f);
+    dz[i] = d;
+    dzc[i] = d * c[i];
+    D[i] = d * s[ch];
+  }
+}
+// BatchNorm / conv-bias gradients from the column sums dS, dH (eval mode: running statistics are constants)
+__global__ void bn_param_grad_kernel(const float* __restrict__ dS, const float* __restrict__ dH, const float* __restrict__ s,
+                                     const float* __restrict__ var, const float* __restrict__ mean, const float* __restrict__ bias, float eps,
+                                     float* __restrict__ g_gamma, float* __restrict__ g_beta, float* __restrict__ g_bias, int C) {
+  EW_LOOP(i, C) {
+    const float rstd = 1.0f / sqrtf(var[i] + eps);
+    if (g_gamma) g_gamma[i] = (dS[i] + dH[i] * (bias[i] - mean[i])) * rstd;
+    if (g_beta) g_beta[i] = dH[i];
+    if (g_bias) g_bias[i] = dH[i] * s[i];
+  }
+}
+// [P][C][T] (the order proj sees) <-> rows [(P,t)][C]
+__global__ void ct_to_rows_kernel(const float* __restrict__ in, float* __restrict__ out, size_t P, int C) {
+  EW_LOOP(i, P * IMU_T * C) {
+    const int c = (int)(i % C);
+    const size_t r = i / C;
+    const int t = (int)(r % IMU_T);
+    const size_t p = r / IMU_T;
+    out[i] = in[(p * C + c) * IMU_T + t];
+  }
+}
+__global__ void rows_to_ct_kernel(const float* __restrict__ in, float* __restrict__ out, size_t P, int C) {
+  EW_LOOP(i, P * IMU_T * C) {
+    const int c = (int)(i % C);
+    const size_t r = i / C;
+    const int t = (int)(r % IMU_T);
+    const size_t p = r / IMU_T;
+    out[(p * C + c) * IMU_T + t] = in[i];
+  }
+}
+
+size_t train_imu_workspace_floats(int P) {
+  const size_t rows = (size_t)P * IMU_T;
+  // x0..x3 and c1..c3 (6 + 2 * 448 per row), X_col (384), dz / dzc / D / g_y (4 * 256), g_xcol (384), flat + g_flat (2 * 256),
+  // column sums, the transposed projection
+  return rows * (6 + 2 * 448 + 384 + 4 * 256 + 384 + 2 * 256) + 1024 + (size_t)2816 * 256;
+}
+
+int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, const float* g_fi, float* g_imu_rows, const ImuGrads& g,
+                  hipStream_t st) {
+  const int pps = (T - 1) / 10, P = B * pps;
+  const size_t rows = (size_t)P * IMU_T;
+  const int C[4] = {6, 64, 128, 256};
+  float* x[4];
+  float* c[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* w = ws;
+  for (int l = 0; l < 4; ++l) { x[l] = w; w += rows * C[l]; }
+  for (int l = 1; l < 4; ++l) { c[l] = w; w += rows * C[l]; }
+  float* xcol = w; w += rows * 384;
+  float* dz = w; w += rows * 256;
+  float* dzc = w; w += rows * 256;
+  float* D = w; w += rows * 256;
+  float* gy = w; w += rows * 256;
+  float* gcol = w; w += rows * 384;
+  float* flat = w; w += rows * 256;     // x3 per pair in (C,T) order: [P][2816], what proj sees
+  float* gflat = w; w += rows * 256;
+  float* dS = w; w += 256;
+  float* dH = w; w += 256;
+  w += 512;
+  float* projT = w;                      // [2816][i_f_len]
+  const int NF = m.i_f_len;
+  // ---- forward, recomputed as GEMMs (X_col rows are padded to ldk = a multiple of 16 columns; the pad is zero on both sides)
+  hipLaunchKernelGGL(imu_window_kernel, EW_GRID(rows * 6), 0, st, imu, x[0], B, T, pps);
+  for (int l = 1; l < 4; ++l) {
+    hipLaunchKernelGGL(im2col3_kernel, EW_GRID(rows * m.ldk[l - 1]), 0, st, x[l - 1], xcol, rows, C[l - 1], m.ldk[l - 1]);
+    gemm_nt(st, xcol, m.ldk[l - 1], m.w[l - 1], m.ldk[l - 1], nullptr, c[l], C[l], (int)rows, C[l], m.ldk[l - 1]);
+    hipLaunchKernelGGL(bn_leaky_fwd_kernel, EW_GRID(rows * C[l]), 0, st, c[l], m.s[l - 1], m.h[l - 1], x[l], rows, C[l]);
+  }
+  hipLaunchKernelGGL(rows_to_ct_kernel, EW_GRID(rows * 256), 0, st, x[3], flat, (size_t)P, 256);
+  // ---- proj backward
+  if (g.proj_w) gemm_tn(st, g_fi, NF, flat, 2816, g.proj_w, 2816, P, NF, 2816);
+  if (g.proj_b) hipLaunchKernelGGL(colsum_kernel, EW_GRID(NF), 0, st, g_fi, g.proj_b, P, NF);
+  relayout_transpose(m.proj_w, projT, NF, 2816, st);                                   // [NF][2816] -> [2816][NF]
+  gemm_nt(st, g_fi, NF, projT, NF, nullptr, gflat, 2816, P, 2816, NF);                  // g_flat = g_fi W
+  hipLaunchKernelGGL(ct_to_rows_kernel, EW_GRID(rows * 256), 0, st, gflat, gy, (size_t)P, 256);
+  // ---- the three conv blocks, last first
+  for (int l = 3; l >= 1; --l) {
+    const int Co = C[l], Ci = C[l - 1], ldk = m.ldk[l - 1];
+    hipLaunchKernelGGL(bn_leaky_bwd_kernel, EW_GRID(rows * Co), 0, st, gy, x[l], c[l], m.s[l - 1], dz, dzc, D, rows, Co);
+    hipLaunchKernelGGL(colsum_kernel, EW_GRID(Co), 0, st, dzc, dS, (int)rows, Co);
+    hipLaunchKernelGGL(colsum_kernel, EW_GRID(Co), 0, st, dz, dH, (int)rows, Co);
+    hipLaunchKernelGGL(bn_param_grad_kernel, EW_GRID(Co), 0, st, dS, dH, m.s[l - 1], m.var[l - 1], m.mean[l - 1], m.bias[l - 1], m.eps, g.gamma[l - 1],
+                       g.beta[l - 1], g.b[l - 1], Co);
+    hipLaunchKernelGGL(im2col3_kernel, EW_GRID(rows * ldk), 0, st, x[l - 1], xcol, rows, Ci, ldk);
+    if (g.w[l - 1]) gemm_tn(st, D, Co, xcol, ldk, g.w[l - 1], 3 * Ci, (int)rows, Co, 3 * Ci);   // [Co][Ci][3]
+    if (l > 1 || g_imu_rows) {
+      gemm_nt(st, D, Co, m.wt[l - 1], Co, nullptr, gcol, 3 * Ci, (int)rows, 3 * Ci, Co);         // g_xcol = D W
+      hipLaunchKernelGGL(col2im3_kernel, EW_GRID(rows * Ci), 0, st, gcol, l > 1 ? gy : g_imu_rows, rows, Ci);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}

@@ -38,6 +38,15 @@ def fuse_param_names(opt):
     return ["Pose_net.fuse.net.0.weight", "Pose_net.fuse.net.0.bias"] if opt.fuse_method in ("soft", "hard") else []
 
 
+def imu_param_names():
+    """Parameters of ``Inertial_net`` (Encoder.py:41-56): three Conv1d + BatchNorm1d pairs and the projection."""
+    names = []
+    for i in (0, 4, 8):
+        names += [f"Inertial_net.encoder_conv.{i}.weight", f"Inertial_net.encoder_conv.{i}.bias",
+                  f"Inertial_net.encoder_conv.{i + 1}.weight", f"Inertial_net.encoder_conv.{i + 1}.bias"]
+    return names + ["Inertial_net.proj.weight", "Inertial_net.proj.bias"]
+
+
 def _tensor_array(names, tensors):
     arr = (_lib.OdevioTensor * len(tensors))()
     for i, (n, t) in enumerate(zip(names, tensors)):
@@ -113,6 +122,38 @@ class _OdeRnnFunction(torch.autograd.Function):
         return (None, None, g_fused, None, g_hc, *grads)
 
 
+class _ImuEncoderFunction(torch.autograd.Function):
+    """imu [B,T,6] (+ the Inertial_net parameters) -> fi [B,(T-1)/10,i_f_len]  (InertialEncoder.forward, eval-mode BatchNorm)."""
+
+    @staticmethod
+    def forward(ctx, model, names, imu, *params):
+        imu = imu.detach().contiguous().float()
+        fi = model.imu_encoder(imu)
+        ctx.model, ctx.names = model, names
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(imu)
+        return fi
+
+    @staticmethod
+    def backward(ctx, g_fi):
+        model = ctx.model
+        (imu,) = ctx.saved_tensors
+        g_fi = g_fi.contiguous().float()
+        grads = [torch.empty(s, device=imu.device, dtype=torch.float32) for s in ctx.param_shapes]
+        model._ensure_plan()
+        _lib.check(model._lib.odevio_imu_encoder_bwd(model._plan, imu.data_ptr(), imu.shape[0], imu.shape[1], g_fi.data_ptr(),
+                                                     _tensor_array(ctx.names, grads), len(grads), model._stream()))
+        return (None, None, None, *grads)
+
+
+def imu_encoder(model, imu):
+    """``model.Inertial_net`` forward WITH an autograd graph to its parameters (the raw IMU samples get no gradient)."""
+    model._ensure_plan()
+    names = imu_param_names()
+    params = dict(model.named_parameters())
+    return _ImuEncoderFunction.apply(model, names, imu, *[params[n] for n in names])
+
+
 class _PoseLossFunction(torch.autograd.Function):
     """100 * MSE(angles) + MSE(translations) (scripts/train_model.py:72-77) with its gradient from the same kernel."""
 
@@ -182,6 +223,7 @@ class PoseNetTrainer:
         self.names = fuse_param_names(opt) + pose_param_names(opt)
         params = dict(model.named_parameters())
         self.params = [params[n] for n in self.names]
+        self._name_set = set(self.names)
         for p in self.params:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise RuntimeError("PoseNetTrainer: parameters must be contiguous fp32 tensors on the GPU (model.cuda())")
@@ -206,8 +248,15 @@ class PoseNetTrainer:
             grads.append(p.grad.contiguous().float())
         stream = model._stream()
         model._ensure_plan()
-        _lib.check(lib.odevio_grad_clip(model._plan, _tensor_array(self.names, grads), len(grads), self.gradient_clip,
-                                        self.norm_coef.data_ptr(), stream))
+        # clip_grad_norm_(model.parameters()): every parameter that has a gradient counts in the norm - with the recipe's frozen
+        # Image_net that is Pose_net (updated below) and Inertial_net (in the norm only: the reference's optimizer does not hold it)
+        extra_names, extra = [], []
+        for n, p in model.named_parameters():
+            if p.grad is not None and n not in self._name_set:
+                extra_names.append(n)
+                extra.append(p.grad.contiguous().float())
+        _lib.check(lib.odevio_grad_clip(model._plan, _tensor_array(self.names + extra_names, grads + extra), len(grads) + len(extra),
+                                        self.gradient_clip, self.norm_coef.data_ptr(), stream))
         self.steps += 1
         for p, g, m, v in zip(self.params, grads, self.exp_avg, self.exp_avg_sq):
             _lib.check(lib.odevio_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr, self.betas[0],
@@ -216,15 +265,24 @@ class PoseNetTrainer:
         _lib.check(lib.odevio_plan_update(model._plan, _tensor_array(self.names, [p.detach() for p in self.params]), len(self.params), stream))
         model._plan_sig = model._signature()
 
-    def step(self, fv, fi, timestamps, gts, hc=None):
+    def zero_all_grads(self):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def step(self, fv, fi, timestamps, gts, hc=None, imu=None):
         """One training step on a batch of features; returns (loss, poses, h_T) - ``loss`` a device scalar
-        (``float(loss)`` synchronises, like the reference's ``pose_loss.item()``)."""
-        self.zero_grad()
+        (``float(loss)`` synchronises, like the reference's ``pose_loss.item()``).  With ``imu`` [B,T,6] instead of ``fi``
+        the inertial encoder is part of the graph: its gradients enter the clipping norm as in the reference's step."""
+        self.zero_all_grads()
+        if imu is not None:
+            if fi is not None:
+                raise ValueError("PoseNetTrainer.step: pass fi or imu, not both")
+            fi = imu_encoder(self.model, imu)
         poses, h_T = pose_net(self.model, fv, fi, timestamps, hc)
         loss = pose_loss(poses, gts)
         loss.backward()
         self.apply_gradients()
-        self.zero_grad()
+        self.zero_all_grads()
         return loss.detach(), poses.detach(), h_T.detach()
 
     @property

@@ -233,3 +233,69 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     losses = [float(trainer.step(fv, fi, ts, gts)[0]) for _ in range(12)]
     model.check()
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_inertial_encoder_backward_matches_autograd_through_the_oracle():
+    opt = default_opt(img_h=64, img_w=128)
+    model, sd = make_model(opt, seed=83)
+    B, T = 3, 41
+    g = torch.Generator().manual_seed(11)
+    imu = torch.randn(B, T, 6, generator=g)
+    gfi = torch.randn(B, (T - 1) // 10, 256, generator=g)
+    names = train.imu_param_names()
+    leaves = {k: v.clone().double().requires_grad_(k in names) for k, v in sd.items() if v.is_floating_point()}   # (running statistics are buffers)
+    fi_ref = oc.inertial_encoder(leaves, imu, dtype=torch.float64)
+    (fi_ref * gfi.double()).sum().backward()
+    fi = train.imu_encoder(model, imu.cuda())
+    (fi * gfi.cuda()).sum().backward()
+    model.check()
+    assert oc.rel_err(fi, fi_ref.detach()) < 1e-4
+    params = dict(model.named_parameters())
+    errs = {n: oc.rel_err(params[n].grad, leaves[n].grad) for n in names}
+    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v < GTOL}
+    assert not bad, f"gradients off by more than {GTOL}: {bad}"
+
+
+def test_trainer_with_the_inertial_encoder_in_the_graph():
+    """The reference's recipe freezes Image_net only: Inertial_net's gradients exist and count in clip_grad_norm_(model.parameters()),
+    while the optimizer holds Pose_net alone (utils/utils.py:116-119)."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    model, sd = make_model(opt, seed=84)
+    B, P = 3, 4
+    g = torch.Generator().manual_seed(12)
+    scale = torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    batches = [(torch.randn(B, P, 512, generator=g), torch.randn(B, 10 * P + 1, 6, generator=g), synth.timestamps(B, P + 1, seed=40 + k),
+                torch.randn(B, P, 6, generator=g) * scale) for k in range(3)]
+    lr, wd, eps, clip = 1e-4, 5e-5, 1e-8, 0.05
+    trainer = train.PoseNetTrainer(model, lr=lr, weight_decay=wd, gradient_clip=clip, eps=eps)
+    inames = train.imu_param_names()
+    leaves = {k: v.clone().float() for k, v in sd.items() if v.is_floating_point()}
+    params = [leaves[n].requires_grad_(True) for n in trainer.names]
+    iparams = [leaves[n].requires_grad_(True) for n in inames]
+    optim = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=wd)
+    ref_norms, ref_losses = [], []
+    for fv, imu, ts, gts in batches:
+        for p in params + iparams:
+            p.grad = None
+        fi = oc.inertial_encoder(leaves, imu)
+        poses, _ = oc.pose_ode_rnn(leaves, fv, fi, ts, None, opt)
+        loss = 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3]) + torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:])
+        loss.backward()
+        ref_norms.append(float(torch.nn.utils.clip_grad_norm_(params + iparams, max_norm=clip)))
+        optim.step()
+        ref_losses.append(float(loss))
+    pose_only = []
+    for fv, imu, ts, gts in batches:
+        loss, _, _ = trainer.step(fv.cuda(), None, ts.cuda(), gts.cuda(), imu=imu.cuda())
+        assert abs(float(loss) - ref_losses[len(pose_only)]) <= 2e-4 * abs(ref_losses[len(pose_only)])
+        pose_only.append(float(trainer.grad_norm))
+    model.check()
+    for a, b in zip(pose_only, ref_norms):
+        assert abs(a - b) <= 2e-3 * b, (pose_only, ref_norms)
+    for n, p in zip(trainer.names, trainer.params):
+        d = (p.detach().cpu() - leaves[n].detach()).abs()
+        assert float(d.max()) <= 1.0 * lr * len(batches), n
+        assert float((d > 0.02 * lr).float().mean()) < 2e-3, n
+    now = dict(model.named_parameters())
+    for n in inames:                                   # Inertial_net is not the optimizer's: unchanged
+        assert torch.equal(now[n].detach().cpu(), sd[n])
