@@ -68,7 +68,7 @@ def conv_roofline(conv_tflops):
     if CONV_MATH == "f32":
         peak, kern, key = FP32_MFMA_PEAK_TFLOPS, "conv_igemm_kernel (conv2..conv6, fp32-input MFMA)", "conv_igemm_kernel [dispatches > 0.4 ms]"
     else:
-        peak, kern, key = F16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT, "conv_f16x2_kernel / conv_f16x2_wide_kernel (conv2..conv6 + visual head)", "conv_f16x2_"
+        peak, kern, key = F16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT, "conv_f16x2_kernel<TERMS, BN, O32, BM> (conv2..conv6 + visual head; tiles of 256 or 192 pixels x 128 or 256 channels)", "conv_f16x2_"
     return {"kernel": kern, "bound": "mfma", "achieved": round(conv_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(conv_tflops / peak, 4), "traffic": pmc_traffic(key),
             "pmc": pmc_derived("conv_f16x2") if CONV_MATH != "f32" else None,
