@@ -216,7 +216,11 @@ class PoseNetTrainer:
         if opt.model_type not in ("ode-rnn", "rnn"):
             raise ValueError("PoseNetTrainer: model_type must be ode-rnn or rnn")
         self.model = model
-        self.lr = float(opt.lr_warmup if lr is None else lr)                       # the reference sets lr per epoch: assign .lr
+        # Two parameter groups like utils/utils.py:116-119: group 0 = Pose_net without the regressor, group 1 = the regressor.
+        # The reference's epoch loop re-assigns the learning rate of group 0 ONLY (train_model.py:211-216, the line for group 1
+        # is commented out), so the regressor keeps lr_warmup for the whole run; set_epoch() reproduces that.
+        self.lr = float(opt.lr_warmup if lr is None else lr)
+        self.lr_regressor = self.lr
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.weight_decay = float(opt.weight_decay if weight_decay is None else weight_decay)
         self.gradient_clip = float(opt.gradient_clip if gradient_clip is None else gradient_clip)
@@ -231,6 +235,18 @@ class PoseNetTrainer:
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.norm_coef = torch.zeros(2, device=self.params[0].device, dtype=torch.float32)   # {total grad norm, clip factor}
         self.steps = 0
+
+    def set_epoch(self, ep):
+        """The reference's per-epoch schedule (train_model.py:25-35, 211-215): lr_warmup for the first epochs_warmup epochs,
+        lr_joint for the next epochs_joint, lr_fine afterwards - applied to parameter group 0 only, as the reference does."""
+        o = self.model.opt
+        if ep < o.epochs_warmup:
+            self.lr = float(o.lr_warmup)
+        elif ep < o.epochs_warmup + o.epochs_joint:
+            self.lr = float(o.lr_joint)
+        else:
+            self.lr = float(o.lr_fine)
+        return self.lr
 
     def zero_grad(self):
         for p in self.params:
@@ -258,8 +274,9 @@ class PoseNetTrainer:
         _lib.check(lib.odevio_grad_clip(model._plan, _tensor_array(self.names + extra_names, grads + extra), len(grads) + len(extra),
                                         self.gradient_clip, self.norm_coef.data_ptr(), stream))
         self.steps += 1
-        for p, g, m, v in zip(self.params, grads, self.exp_avg, self.exp_avg_sq):
-            _lib.check(lib.odevio_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr, self.betas[0],
+        for n, p, g, m, v in zip(self.names, self.params, grads, self.exp_avg, self.exp_avg_sq):
+            lr = self.lr_regressor if n.startswith("Pose_net.regressor.") else self.lr
+            _lib.check(lib.odevio_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, self.betas[0],
                                             self.betas[1], self.eps, self.weight_decay, self.steps, self.norm_coef.data_ptr(), stream))
         # the kernels read their own layouts of these parameters (column shards, transposes): refresh them in place
         _lib.check(lib.odevio_plan_update(model._plan, _tensor_array(self.names, [p.detach() for p in self.params]), len(self.params), stream))

@@ -148,3 +148,24 @@ def test_flownet_checkpoint_loads_by_key_intersection():
     bad = {"state_dict": {"conv1.0.weight": torch.zeros(64, 6, 3, 3)}}
     with pytest.raises(RuntimeError):
         weights.load_flownet_checkpoint(model, bad)
+
+
+def test_trainer_schedule_and_parameter_groups_follow_the_reference():
+    """PoseNetTrainer.set_epoch = update_status (scripts/train_model.py:25-35) applied to parameter group 0 only (:214-215);
+    needs no GPU: the schedule is host logic."""
+    from odevio_amd import default_opt, train
+
+    class _Model:
+        opt = default_opt()
+
+    t = train.PoseNetTrainer.__new__(train.PoseNetTrainer)
+    t.model = _Model()
+    t.lr = t.lr_regressor = 1e-4
+    o = _Model.opt
+    assert t.set_epoch(0) == o.lr_warmup and t.set_epoch(o.epochs_warmup - 1) == o.lr_warmup
+    assert t.set_epoch(o.epochs_warmup) == o.lr_joint
+    assert t.set_epoch(o.epochs_warmup + o.epochs_joint - 1) == o.lr_joint
+    assert t.set_epoch(o.epochs_warmup + o.epochs_joint) == o.lr_fine
+    assert t.lr_regressor == 1e-4          # the reference never re-assigns group 1
+    names = train.fuse_param_names(default_opt(fuse_method="soft")) + train.pose_param_names(default_opt(fuse_method="soft"))
+    assert sum(n.startswith("Pose_net.regressor.") for n in names) == 4 and "Pose_net.fuse.net.0.weight" in names
