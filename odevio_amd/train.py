@@ -306,3 +306,24 @@ class PoseNetTrainer:
     def grad_norm(self):
         """Total gradient norm of the last step (device scalar)."""
         return self.norm_coef[0]
+
+
+def train_epoch(model, trainer, loader, log=None, log_every=20):
+    """One epoch of the reference's ``train()`` (scripts/train_model.py:48-95) on libodevio: ``loader`` yields
+    ``(imgs [B,S,3,H,W], imus [B,10(S-1)+1,6], gts [B,S-1,6], timestamps [B,S], folder)`` like the reference's ``DataLoader``;
+    every batch is one ``PoseNetTrainer.step`` with the image features from ``model.image_encoder`` (the recipe's frozen
+    ``Image_net``; eval-mode BatchNorm, no dropout - see the module docstring) and the inertial encoder inside the graph.
+    Returns the mean pose loss like the reference.  ``log(message)`` receives the reference's per-iteration line."""
+    losses = []
+    n = len(loader) if hasattr(loader, "__len__") else None
+    for i, (imgs, imus, gts, timestamps, _folder) in enumerate(loader):
+        dev = next(model.parameters()).device
+        imgs, imus = imgs.to(dev).float(), imus.to(dev).float()
+        gts, timestamps = gts.to(dev).float(), timestamps.to(dev).float()
+        with torch.no_grad():
+            fv = model.image_encoder(imgs)
+        loss, _, _ = trainer.step(fv, None, timestamps, gts, imu=imus)
+        if log is not None and i % log_every == 0:
+            log(f"iters: {i + 1}/{n if n is not None else '?'}, pose loss: {float(loss):.6f}, grad norm: {float(trainer.grad_norm):.4f}")
+        losses.append(loss)
+    return float(torch.stack(losses).mean()) if losses else float("nan")

@@ -154,7 +154,7 @@ def _torch_reference_training(sd, opt, names, batches, lr, weight_decay, clip, e
         loss.backward()
         norms.append(float(torch.nn.utils.clip_grad_norm_(params, max_norm=clip)))
         optim.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     return {n: p.detach() for n, p in zip(names, params)}, losses, norms
 
 
@@ -178,7 +178,7 @@ def test_pose_net_trainer_follows_torch_adam_on_the_oracle(cfg, clip):
     losses, norms = [], []
     for fv, fi, ts, gts in batches:
         loss, poses, _ = trainer.step(fv.cuda(), fi.cuda(), ts.cuda(), gts.cuda())
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         norms.append(float(trainer.grad_norm))
     model.check()
     for a, b in zip(losses, ref_losses):           # the loss of step k sees the parameters of steps < k: the updates took effect
@@ -299,3 +299,22 @@ def test_trainer_with_the_inertial_encoder_in_the_graph():
     now = dict(model.named_parameters())
     for n in inames:                                   # Inertial_net is not the optimizer's: unchanged
         assert torch.equal(now[n].detach().cpu(), sd[n])
+
+
+def test_train_epoch_runs_the_reference_loop_end_to_end():
+    """train.train_epoch = scripts/train_model.py:48-95 on the device path: frames and IMU samples in, encoders, pose net,
+    loss, backward, clip, Adam per batch.  A fixed pair of batches, several epochs: the loss goes down, nothing fails."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    model, _ = make_model(opt, seed=85)
+    batches = []
+    for k in range(2):
+        img, imu, ts = synth.batch(2, 4, 64, 128, seed=50 + k)
+        g = torch.Generator().manual_seed(60 + k)
+        gts = torch.randn(2, 3, 6, generator=g) * torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+        batches.append((img, imu, gts, ts, "synthetic"))
+    trainer = train.PoseNetTrainer(model, lr=1e-3)
+    lines = []
+    means = [train.train_epoch(model, trainer, batches, log=lines.append, log_every=1) for _ in range(6)]
+    model.check()
+    assert all(m == m for m in means) and means[-1] < 0.8 * means[0], means
+    assert len(lines) == 12 and "pose loss" in lines[0]
