@@ -47,3 +47,18 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     arr = (_lib.OdevioTensor * 1)()
     rc = lib.odevio_plan_create(ctypes.byref(cfg), arr, 1, None, ctypes.byref(plan))
     assert rc == _lib.ERR_BAD_ARG and b"size mismatch" in lib.odevio_last_error()
+
+
+def test_training_entry_points_reject_bad_arguments_without_a_gpu():
+    """The optimizer-step entry points check their arguments before they touch the device."""
+    lib = _lib.load()
+    f = ctypes.c_float
+    one = ctypes.c_void_p(16)   # never dereferenced: the checks below fail first
+    assert lib.odevio_adam_step(None, None, None, None, 0, f(1e-4), f(0.9), f(0.999), f(1e-8), f(0.0), 1, None, None) == _lib.ERR_BAD_ARG
+    assert lib.odevio_adam_step(one, one, one, one, 8, f(1e-4), f(0.9), f(0.999), f(1e-8), f(0.0), 0, None, None) == _lib.ERR_BAD_ARG   # step counts from 1
+    assert lib.odevio_adam_step(one, one, one, one, 8, f(1e-4), f(1.0), f(0.999), f(1e-8), f(0.0), 1, None, None) == _lib.ERR_BAD_ARG   # beta1 < 1
+    assert b"odevio_adam_step" in lib.odevio_last_error()
+    assert lib.odevio_grad_clip(None, None, 0, f(5.0), None, None) == _lib.ERR_BAD_ARG
+    assert lib.odevio_plan_update(None, None, 0, None) == _lib.ERR_BAD_ARG
+    assert lib.odevio_fuse_bwd(None, None, None, 0, None, None, None, None, 0, None) == _lib.ERR_BAD_ARG
+    assert lib.odevio_imu_encoder_bwd(None, None, 0, 0, None, None, 0, None) == _lib.ERR_BAD_ARG
