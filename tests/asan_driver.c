@@ -43,6 +43,11 @@ int main(void) {
   EXPECT(odevio_ode_rnn_bwd(NULL, x, x, NULL, 1, 1, x, NULL, NULL, NULL, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_cde_fwd(NULL, x, 1, 2, NULL, 1, NULL, x, x, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_check(NULL, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_fuse_bwd(NULL, x, x, 1, x, x, x, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_imu_encoder_bwd(NULL, x, 1, 11, x, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_grad_clip(NULL, NULL, 0, 5.0f, x, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_adam_step(x, x, x, x, 4, 1e-4f, 0.9f, 0.999f, 1e-8f, 0.0f, 0, NULL, NULL) == ODEVIO_ERR_BAD_ARG);   /* step counts from 1 */
+  EXPECT(odevio_plan_update(NULL, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_resize_u8(NULL, 1, 4, 4, NULL, 2, 2, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   odevio_plan_destroy(NULL);
   /* resize tables: KITTI width and height, an upscale, a degenerate 1-pixel axis; capacity checked */
