@@ -52,8 +52,10 @@ enum odevio_activation { ODEVIO_ACT_TANH = 0, ODEVIO_ACT_RELU = 1, ODEVIO_ACT_LE
 enum odevio_solver { ODEVIO_DOPRI5 = 0, ODEVIO_HEUN = 1, ODEVIO_TSIT5 = 2, ODEVIO_EULER = 3, ODEVIO_RK4 = 4, ODEVIO_RK4_CLASSIC = 5 };
 /* reference src/models/PoseODERNN.py:139-148 */
 enum odevio_rnn { ODEVIO_RNN_TANH = 0, ODEVIO_RNN_GRU = 1 };
-/* reference src/models/FusionModule.py:17-23 ("hard" is stochastic: host-side only) */
-enum odevio_fuse { ODEVIO_FUSE_CAT = 0, ODEVIO_FUSE_SOFT = 1 };
+/* reference src/models/FusionModule.py:17-29.  "hard" is stochastic (F.gumbel_softmax(..., hard=True) under torch's generator):
+ * the device path draws the same distribution from its own counter-based generator (odevio_set_seed): no bit-level parity
+ * with the reference is possible, the distribution and the arithmetic around the mask are tested. */
+enum odevio_fuse { ODEVIO_FUSE_CAT = 0, ODEVIO_FUSE_SOFT = 1, ODEVIO_FUSE_HARD = 2 };
 /* reference src/models/DeepVIO.py:45-59 */
 enum odevio_model { ODEVIO_MODEL_ODE_RNN = 0, ODEVIO_MODEL_RNN = 1, ODEVIO_MODEL_CDE = 2 };
 
@@ -176,6 +178,10 @@ int odevio_ode_rnn_bwd(odevio_plan* plan, const float* fused, const float* ts, c
  * {100 * angle_loss + translation_loss, angle_loss, translation_loss} with MSE over the first / last three pose columns of
  * n_rows = B*P rows; grad_poses [n_rows,6] = d loss3[0] / d poses, or NULL. */
 int odevio_pose_loss(const float* poses, const float* gts, int32_t n_rows, float* loss3, float* grad_poses, void* stream);
+
+/* Seed of the plan's random stream (Philox 4x32-10; fuse_method "hard" draws its Gumbel noise from it, one counter block per
+ * call).  The same seed gives the same sequence of masks; plans start at seed 0. */
+int odevio_set_seed(odevio_plan* plan, uint64_t seed);
 
 /* FusionModule backward (reference src/models/FusionModule.py:17-23; autograd in scripts/train_model.py:78): fv [P,v], fi [P,i],
  * grad_fused [P,v+i] -> grad_fv [P,v], grad_fi [P,i] (either may be NULL) and, for fuse_method "soft", the gradients of

@@ -12,7 +12,7 @@ ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_MISSING_WEIGHT, ERR_HIP, ERR_NO_DEVICE, ERR_TI
 ACTIVATIONS = {"tanh": 0, "relu": 1, "leaky_relu": 2, "softplus": 3}
 SOLVERS = {"dopri5": 0, "heun": 1, "tsit5": 2, "euler": 3, "rk4": 4, "runge_kutta": 4, "rk4_classic": 5}
 RNN_TYPES = {"rnn": 0, "gru": 1}
-FUSE_METHODS = {"cat": 0, "soft": 1}
+FUSE_METHODS = {"cat": 0, "soft": 1, "hard": 2}
 MODEL_TYPES = {"ode-rnn": 0, "rnn": 1, "cde": 2}
 # --dtype -> odevio_arith: fp32 = fp32-grade products on the fp16 MFMA (two-piece operands), fp32_mfma = the fp32-input MFMA,
 # fp16 / bf16 = the reduced-precision encoder (its operand type on gfx950 is fp16: same MFMA rate as bf16, 3 more bits)
@@ -25,7 +25,7 @@ SYMBOLS = [
     "odevio_ode_steps", "odevio_ode_rnn_fwd", "odevio_cde_fwd", "odevio_forward", "odevio_profile_enable", "odevio_profile_read", "odevio_debug_stamps",
     "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func", "odevio_cde_last_ms",
     "odevio_ode_rnn_bwd", "odevio_pose_loss", "odevio_resize_u8", "odevio_resize_table",
-    "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update", "odevio_imu_encoder_bwd",
+    "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update", "odevio_imu_encoder_bwd", "odevio_set_seed",
 ]
 
 
@@ -114,6 +114,7 @@ def load():
     lib.odevio_adam_step.argtypes = [fp, fp, fp, fp, ctypes.c_int64, f32, f32, f32, f32, f32, i32, fp, vp]
     lib.odevio_plan_update.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_imu_encoder_bwd.argtypes = [vp, fp, i32, i32, fp, ctypes.POINTER(OdevioTensor), i32, vp]
+    lib.odevio_set_seed.argtypes = [vp, ctypes.c_uint64]
     lib.odevio_resize_table.argtypes = [i32, i32, vp, vp, vp, i32]
     lib.odevio_resize_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.odevio_cde_func.argtypes = [vp, fp, fp, i32, i32, i32, fp, vp]

@@ -101,6 +101,7 @@ struct odevio_plan {
   float *imu_wref[3] = {}, *imu_var[3] = {}, *imu_mean[3] = {}, *imu_bias[3] = {};   // backward: reference-layout weights (rows padded to 16), BatchNorm statistics
   float *proj_w = nullptr, *proj_b = nullptr;
   float *fuse_w = nullptr, *fuse_b = nullptr, *fuse_w_t = nullptr;
+  unsigned long long seed = 0, rng_calls = 0;   // fuse_method hard: Philox key and the per-call counter block
   float *reg_w0 = nullptr, *reg_b0 = nullptr, *reg_w2 = nullptr, *reg_b2 = nullptr;
   // integrator
   int nlin = 0;
@@ -344,14 +345,13 @@ static int validate(const odevio_config& c) {
     if (c.cde_solver != ODEVIO_DOPRI5 && c.cde_solver != ODEVIO_RK4 && c.cde_solver != ODEVIO_EULER)
       return fail(ODEVIO_ERR_BAD_ARG, "Solver not supported");
     if (c.fuse_method != ODEVIO_FUSE_CAT && c.fuse_method != ODEVIO_FUSE_SOFT)
-      return fail(ODEVIO_ERR_UNSUPPORTED, "fuse method %d has no deterministic device path", c.fuse_method);
+      return fail(ODEVIO_ERR_UNSUPPORTED, "fuse method %d is not supported on the Neural-CDE path", c.fuse_method);
     if (c.img_h < 64 || c.img_w < 64) return fail(ODEVIO_ERR_BAD_ARG, "image size %dx%d too small", c.img_h, c.img_w);
     if (c.v_f_len % 4 || c.i_f_len % 4) return fail(ODEVIO_ERR_UNSUPPORTED, "feature lengths must be multiples of 4");
     return 0;
   }
   if (c.img_h < 64 || c.img_w < 64) return fail(ODEVIO_ERR_BAD_ARG, "image size %dx%d too small", c.img_h, c.img_w);
-  if (c.fuse_method != ODEVIO_FUSE_CAT && c.fuse_method != ODEVIO_FUSE_SOFT)
-    return fail(ODEVIO_ERR_UNSUPPORTED, "fuse method %d has no deterministic device path", c.fuse_method);
+  if (c.fuse_method < ODEVIO_FUSE_CAT || c.fuse_method > ODEVIO_FUSE_HARD) return fail(ODEVIO_ERR_BAD_ARG, "Fusion method not supported");
   if (c.ode_activation < 0 || c.ode_activation > 3) return fail(ODEVIO_ERR_BAD_ARG, "Activation function not supported");
   if (c.ode_solver < 0 || c.ode_solver > ODEVIO_RK4_CLASSIC) return fail(ODEVIO_ERR_BAD_ARG, "Solver not supported");
   if (c.rnn_type != ODEVIO_RNN_TANH && c.rnn_type != ODEVIO_RNN_GRU) return fail(ODEVIO_ERR_BAD_ARG, "RNN type not supported");
@@ -385,6 +385,12 @@ static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
     PN(upload(p, &p->fuse_w, w, st));
     PN(upload(p, &p->fuse_w_t, transposed(w, F, F), st));   // backward: g_c += g_w W
     PN(wt.get("Pose_net.fuse.net.0.bias", F, bias));
+    PN(upload(p, &p->fuse_b, bias, st));
+  }
+  if (p->cfg.fuse_method == ODEVIO_FUSE_HARD) {   // Linear(F, 2F): logits (keep, drop) per feature, interleaved (FusionModule.py:14,26)
+    PN(wt.get("Pose_net.fuse.net.0.weight", (int64_t)2 * F * F, w));
+    PN(upload(p, &p->fuse_w, w, st));
+    PN(wt.get("Pose_net.fuse.net.0.bias", (int64_t)2 * F, bias));
     PN(upload(p, &p->fuse_b, bias, st));
   }
   PN(wt.get("Pose_net.regressor.0.weight", (int64_t)128 * F, w));
@@ -1110,6 +1116,15 @@ static int fuse_from_cat(odevio_plan* p, const float* fcat, int P, float* fused,
     if (fused != fcat) HIPCHK(hipMemcpyAsync(fused, fcat, (size_t)P * F * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
   }
+  if (p->cfg.fuse_method == ODEVIO_FUSE_HARD) {
+    // logits [P][2F] = cat W^T + b; feature j is kept when logit(2j) + g0 >= logit(2j+1) + g1 with g ~ Gumbel(0, 1): the one-hot
+    // forward value of F.gumbel_softmax(..., tau=1, hard=True)[..., 0] (FusionModule.py:24-29; argmax takes index 0 on a tie)
+    int rc = ensure(p->train_aux, (size_t)P * 2 * F);
+    if (rc) return rc;
+    if ((rc = run_gemm(p, fcat, P, F, p->fuse_w, 2 * F, nullptr, p->fuse_b, nullptr, 0, p->train_aux.p, 2 * F, EPI_NONE, 0.f, st))) return rc;
+    launch_hard_mask(fcat, p->train_aux.p, fused, (size_t)P * F, p->seed, p->rng_calls++, st);
+    return hipGetLastError() == hipSuccess ? 0 : fail(ODEVIO_ERR_HIP, "hard fusion: launch failed");
+  }
   return run_gemm(p, fcat, P, F, p->fuse_w, F, nullptr, p->fuse_b, fcat, F, fused, F, EPI_NONE, 0.f, st);
 }
 
@@ -1671,6 +1686,7 @@ extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, 
   // first pass: every tensor present with the right size (nothing is written before that is known)
   std::vector<std::pair<std::string, int64_t>> need;
   if (p->cfg.fuse_method == ODEVIO_FUSE_SOFT) { need.push_back({"Pose_net.fuse.net.0.weight", (int64_t)F * F}); need.push_back({"Pose_net.fuse.net.0.bias", F}); }
+  if (p->cfg.fuse_method == ODEVIO_FUSE_HARD) { need.push_back({"Pose_net.fuse.net.0.weight", (int64_t)2 * F * F}); need.push_back({"Pose_net.fuse.net.0.bias", (int64_t)2 * F}); }
   need.push_back({"Pose_net.regressor.0.weight", (int64_t)128 * F}); need.push_back({"Pose_net.regressor.0.bias", 128});
   need.push_back({"Pose_net.regressor.2.weight", 6 * 128}); need.push_back({"Pose_net.regressor.2.bias", 6});
   if (p->cfg.model_type == ODEVIO_MODEL_ODE_RNN)
@@ -1696,6 +1712,10 @@ extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, 
     copy(p->fuse_w, w, (size_t)F * F);
     relayout_transpose(w, p->fuse_w_t, F, F, st);
     copy(p->fuse_b, src("Pose_net.fuse.net.0.bias", F), F);
+  }
+  if (p->cfg.fuse_method == ODEVIO_FUSE_HARD) {
+    copy(p->fuse_w, src("Pose_net.fuse.net.0.weight", (int64_t)2 * F * F), (size_t)2 * F * F);
+    copy(p->fuse_b, src("Pose_net.fuse.net.0.bias", (int64_t)2 * F), (size_t)2 * F);
   }
   {
     const float* w = src("Pose_net.regressor.0.weight", (int64_t)128 * F);
@@ -1734,11 +1754,20 @@ extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, 
   return 0;
 }
 
+extern "C" int odevio_set_seed(odevio_plan* p, uint64_t seed) {
+  ARGCHK(p, "odevio_set_seed: bad argument");
+  p->seed = seed;
+  p->rng_calls = 0;
+  return 0;
+}
+
 extern "C" int odevio_fuse_bwd(odevio_plan* p, const float* fv, const float* fi, int32_t P, const float* grad_fused, float* grad_fv,
                                float* grad_fi, const odevio_tensor* grads, int32_t n_grads, void* stream) {
   ARGCHK(p && fv && fi && grad_fused && P > 0 && n_grads >= 0 && (grads || n_grads == 0), "odevio_fuse_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   POLL(p, st);
+  if (p->cfg.fuse_method == ODEVIO_FUSE_HARD)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_fuse_bwd: fuse_method 'hard' (straight-through gumbel-softmax) has no backward here");
   const int F = p->F;
   const bool soft = p->cfg.fuse_method == ODEVIO_FUSE_SOFT;
   float *gW = nullptr, *gb = nullptr;

@@ -185,3 +185,7 @@ __device__ __forceinline__ float apply_epi(float v, int act, float slope) {
   if (act == EPI_TANH) return tanhf(v);
   return v;
 }
+
+// fuse_method "hard" (api.hip fuse_from_cat): fused = cat * [logit(2j) + g0 >= logit(2j+1) + g1], Gumbel noise from Philox 4x32-10
+void launch_hard_mask(const float* cat, const float* logits, float* fused, size_t n, unsigned long long seed, unsigned long long call,
+                      hipStream_t st);

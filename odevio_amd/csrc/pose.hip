@@ -135,3 +135,49 @@ hipError_t launch_path_accu(const void* poses, int is_f64, const int64_t* offset
                        carry, out);
   return hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FusionModule "hard" (reference src/models/FusionModule.py:24-29): mask = F.gumbel_softmax(logits.view(..., F, 2), tau=1,
+// hard=True)[..., 0], fused = cat * mask.  The forward value of the straight-through estimator is the one-hot arg-max of
+// logits + Gumbel noise, so feature j is kept iff l0 + g0 >= l1 + g1.  torch draws g = -log(Exponential(1)) from its own
+// generator; here the two uniforms of element j come from Philox 4x32-10 keyed by the plan's seed, counter = (element / 2,
+// call): reproducible per seed, never bit-equal to torch.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ float gumbel_from_bits(unsigned bits) {
+  const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1), 24 bits
+  return -logf(-logf(u));
+}
+__global__ void hard_mask_kernel(const float* __restrict__ cat, const float* __restrict__ logits, float* __restrict__ fused, size_t n,
+                                 unsigned long long seed, unsigned long long call) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n + 1) / 2; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned c[4] = {(unsigned)i, (unsigned)(i >> 32), (unsigned)call, (unsigned)(call >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const size_t j = 2 * i + e;
+      if (j < n) {
+        const float keep = logits[2 * j] + gumbel_from_bits(c[2 * e]), drop = logits[2 * j + 1] + gumbel_from_bits(c[2 * e + 1]);
+        fused[j] = keep >= drop ? cat[j] : 0.f;
+      }
+    }
+  }
+}
+void launch_hard_mask(const float* cat, const float* logits, float* fused, size_t n, unsigned long long seed, unsigned long long call,
+                      hipStream_t st) {
+  const unsigned blocks = (unsigned)std::min<size_t>(((n + 1) / 2 + 255) / 256, 2048);
+  hipLaunchKernelGGL(hard_mask_kernel, dim3(blocks), dim3(256), 0, st, cat, logits, fused, n, seed, call);
+}

@@ -197,7 +197,7 @@ class DeepVIO(nn.Module):
         c.struct_size = ctypes.sizeof(_lib.OdevioConfig)
         c.model_type = _lib.MODEL_TYPES[o.model_type]
         c.img_h, c.img_w, c.v_f_len, c.i_f_len = o.img_h, o.img_w, o.v_f_len, o.i_f_len
-        c.fuse_method = _lib.FUSE_METHODS.get(o.fuse_method, 0)  # "hard": mask on the host, cat on the device
+        c.fuse_method = _lib.FUSE_METHODS[o.fuse_method]
         c.ode_hidden_dim, c.ode_fn_num_layers = o.ode_hidden_dim, o.ode_fn_num_layers
         c.ode_activation = _lib.ACTIVATIONS[o.ode_activation_fn]
         c.ode_solver = _lib.SOLVERS[o.ode_solver]
@@ -269,13 +269,10 @@ class DeepVIO(nn.Module):
             warnings.warn("odevio_amd.DeepVIO.forward computes inference (eval-mode BatchNorm, no autograd graph) even in "
                           "train(); use odevio_amd.train.OdeRnnFunction for gradients through the integrator", stacklevel=2)
             self._warned_train = True
-        if img.dtype == torch.uint8 and (self.opt.model_type == "cde" or self.opt.fuse_method == "hard"):
-            raise ValueError("uint8 frames are supported for model_type ode-rnn / rnn with cat or soft fusion")
+        if img.dtype == torch.uint8 and self.opt.model_type == "cde":
+            raise ValueError("uint8 frames are supported for model_type ode-rnn / rnn")
         if self.opt.model_type == "cde":
             return self.pose_cde(self.image_encoder(img), self.imu_encoder(imu), timestamps, hc)
-        if self.opt.fuse_method == "hard":
-            fv, fi = self.image_encoder(img), self.imu_encoder(imu)
-            return self.pose_net(fv, fi, timestamps, hc)
         u8 = img.dtype == torch.uint8
         if u8:
             # the loader's frames before ToTensor() - 0.5 (reference src/data/KITTI_eval.py:97-110): [B,S,H,W,3] uint8;
@@ -337,15 +334,15 @@ class DeepVIO(nn.Module):
                                                     self._stream()))
         return fi
 
+    def set_seed(self, seed):
+        """Seed of the plan's random stream (fuse_method "hard" draws its Gumbel noise from it): same seed, same masks."""
+        self._ensure_plan()
+        _lib.check(self._lib.odevio_set_seed(self._plan, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
     def fuse(self, fv, fi):
         self._ensure_plan()
         fv, fi = self._dev(fv, "fv"), self._dev(fi, "fi")
-        if self.opt.fuse_method == "hard":
-            # stochastic Gumbel mask (FusionModule.py:24-29): host-side torch on the device, no parity claim
-            cat = torch.cat((fv, fi), -1)
-            w = torch.nn.functional.linear(cat, self.Pose_net.fuse.net[0].weight, self.Pose_net.fuse.net[0].bias)
-            mask = torch.nn.functional.gumbel_softmax(w.view(*cat.shape, 2), tau=1, hard=True, dim=-1)
-            return cat * mask[..., 0]
+        # ("hard": the Gumbel mask of FusionModule.py:24-29 drawn on the device from the plan's own generator - set_seed())
         P = fv.shape[0] * fv.shape[1]
         out = torch.empty(fv.shape[0], fv.shape[1], fv.shape[2] + fi.shape[2], device=fv.device, dtype=torch.float32)
         _lib.check(self._lib.odevio_fuse_fwd(self._plan, fv.data_ptr(), fi.data_ptr(), P, out.data_ptr(), self._stream()))

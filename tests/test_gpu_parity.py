@@ -138,6 +138,44 @@ def test_image_encoder_golden_small(dev, golden_dir):
     assert_close(c1.permute(0, 3, 1, 2)[:, ::8, ::8, ::8], torch.from_numpy(g["conv1_sample"]), what="conv1 vs reference")
 
 
+def test_hard_fusion_is_a_gumbel_argmax_drawn_on_the_device(dev):
+    """FusionModule "hard" (FusionModule.py:24-29): mask = gumbel_softmax(logits.view(..., F, 2), tau=1, hard=True)[..., 0], i.e. feature j
+    is kept with probability sigmoid(l0 - l1).  Stochastic under torch's generator in the reference, so there is no bit-level
+    parity: checked here are the arithmetic around the mask, the distribution, and reproducibility per seed."""
+    opt = default_opt(img_h=64, img_w=128, fuse_method="hard")
+    model, _ = make_model(opt, seed=31)
+    F = 768
+    d = torch.linspace(-3.0, 3.0, F)
+    with torch.no_grad():
+        model.Pose_net.fuse.net[0].weight.zero_()               # logits = bias: (d_j, 0) per feature, independent of the input
+        b = torch.zeros(2 * F)
+        b[0::2] = d
+        model.Pose_net.fuse.net[0].bias.copy_(b)
+    g = torch.Generator().manual_seed(3)
+    fv, fi = torch.randn(64, 16, 512, generator=g).cuda(), torch.randn(64, 16, 256, generator=g).cuda()
+    cat = torch.cat((fv, fi), -1)
+    model.set_seed(7)
+    a = model.fuse(fv, fi)
+    keep = a != 0
+    assert torch.equal(a, torch.where(keep, cat, torch.zeros_like(cat)))       # fused = cat * one-hot mask, nothing else
+    freq = keep.float().mean(dim=(0, 1)).cpu()
+    p = torch.sigmoid(d)
+    sigma = (p * (1 - p) / (64 * 16)).sqrt()
+    assert float(((freq - p).abs() / sigma).max()) < 5.5, float(((freq - p).abs() / sigma).max())
+    assert abs(float((freq - p).mean())) < 3e-3                                  # no bias over the 768 features
+    model.set_seed(7)
+    assert torch.equal(model.fuse(fv, fi), a)                                    # same seed, same mask
+    b2 = model.fuse(fv, fi)
+    assert not torch.equal(b2, a)                                                # the next call draws fresh noise
+    model.set_seed(8)
+    assert not torch.equal(model.fuse(fv, fi), a)
+    # and the whole forward runs on the device path with it
+    img, imu, ts = synth.batch(2, 3, 64, 128, seed=4)
+    poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    assert torch.isfinite(poses).all() and torch.isfinite(h).all()
+
+
 def test_inertial_encoder(dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "inertial_encoder.npz"))
     opt = default_opt(img_h=64, img_w=128)
