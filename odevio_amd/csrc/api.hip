@@ -1097,6 +1097,13 @@ static int imu_encoder(odevio_plan* p, const float* imu, int B, int T, float* fi
   a.s1 = p->imu_s[0]; a.h1 = p->imu_h[0]; a.s2 = p->imu_s[1]; a.h2 = p->imu_h[1]; a.s3 = p->imu_s[2]; a.h3 = p->imu_h[2];
   a.out = p->imu_act.p; a.B = B; a.T = T; a.pairs_per_seq = pps;
   launch_imu_convs(a, st);
+  static const bool old_gemm = getenv("ODEVIO_IMU_PROJ_IGEMM") != nullptr;   // diagnostic: the implicit-GEMM kernel (split-K 8, 32 workgroups, 0.66 ms)
+  if (!old_gemm) {
+    // 160 x 2816 -> 256: 160 workgroups of the skinny fp32-MFMA GEMM.  This branch runs on the side stream UNDER conv1, whose
+    // persistent workgroups own every CU: the shorter it is, the less it holds back the CUs it shares
+    skinny_linear(p->imu_act.p, 2816, p->proj_w, 2816, p->proj_b, fi, ld_fi, P, p->cfg.i_f_len, 2816, st);
+    return hipGetLastError() == hipSuccess ? 0 : fail(ODEVIO_ERR_HIP, "InertialEncoder projection: launch failed");
+  }
   return run_gemm(p, p->imu_act.p, P, 2816, p->proj_w, p->cfg.i_f_len, nullptr, p->proj_b, nullptr, 0, fi, ld_fi,
                   EPI_NONE, 0.f, st, slabs);
 }
@@ -1296,6 +1303,15 @@ static int run_rows(odevio_plan* p, int mode, const float* y, const float* t0, c
 static int regress(odevio_plan* p, const float* seq, int M, float* poses, hipStream_t st) {
   int rc;
   if ((rc = ensure(p->reg_hid, (size_t)M * 128))) return rc;
+  static const bool old_gemm = getenv("ODEVIO_REGRESSOR_IGEMM") != nullptr;   // diagnostic: the implicit-GEMM kernel with split-K (0.057 ms)
+  if (!old_gemm && p->F % 16 == 0) {
+    // Linear(F, 128) + LeakyReLU(0.1) + Linear(128, 6) (PoseODERNN.py:64-67) on the skinny fp32-MFMA GEMM: M is B * (S - 1) rows,
+    // three short launches behind the integrator on the critical path
+    skinny_linear(seq, p->F, p->reg_w0, p->F, p->reg_b0, p->reg_hid.p, 128, M, 128, p->F, st);
+    leaky_inplace(p->reg_hid.p, (size_t)M * 128, 0.1f, st);
+    skinny_linear(p->reg_hid.p, 128, p->reg_w2, 128, p->reg_b2, poses, 6, M, 6, 128, st);
+    return hipGetLastError() == hipSuccess ? 0 : fail(ODEVIO_ERR_HIP, "regressor: launch failed");
+  }
   if ((rc = run_gemm(p, seq, M, p->F, p->reg_w0, 128, nullptr, p->reg_b0, nullptr, 0, p->reg_hid.p, 128, EPI_LEAKY, 0.1f, st)))
     return rc;
   return run_gemm(p, p->reg_hid.p, M, 128, p->reg_w2, 6, nullptr, p->reg_b2, nullptr, 0, poses, 6, EPI_NONE, 0.f, st);

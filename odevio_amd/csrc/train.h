@@ -72,3 +72,5 @@ size_t train_imu_workspace_floats(int P);
 // imu [B][T][6], g_fi [B * (T-1)/10][i_f_len] contiguous; g_imu_rows (optional) [(pair, t)][6]: gradient w.r.t. the windowed samples
 int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, const float* g_fi, float* g_imu_rows, const ImuGrads& g,
                   hipStream_t st);
+void skinny_linear(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, hipStream_t st);
+void leaky_inplace(float* x, size_t n, float slope, hipStream_t st);

@@ -827,3 +827,10 @@ int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, 
   }
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
+
+// out [M][ldo] = A [M][lda] W^T + bias on the skinny fp32-MFMA GEMM above (K % 16 == 0): for forward-path projections whose
+// M is a few hundred rows (the InertialEncoder's proj: 160 x 2816 -> 256)
+void skinny_linear(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, hipStream_t st) {
+  gemm_nt(st, A, lda, W, ldw, bias, out, ldo, M, N, K);
+}
+void leaky_inplace(float* x, size_t n, float slope, hipStream_t st) { hipLaunchKernelGGL(leaky_kernel, EW_GRID(n), 0, st, x, n, slope); }
