@@ -14,6 +14,7 @@ from oracle import odevio_oracle as oc
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -118,6 +119,34 @@ def test_two_phase_tile_plan_matches_single_phase(dev, monkeypatch):
     model.check()
     assert torch.equal(two, single)
     assert_close(two, oc.image_encoder(sd, img), what="fv, two-phase plan")
+
+
+def test_64_bit_dma_addressing_form_of_the_conv_kernel(dev, tmp_path):
+    """The production form of conv_f16x2_kernel addresses its DMA sources as scalar base + 32-bit offset; buffers of 4 GB and
+    more (very large batches) fall back to the 64-bit form (two pointers, range compares), which no default-size test reaches.
+    ODEVIO_CONV_OFF64 selects it; the variable is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    out = str(tmp_path / "fv.pt")
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "from odevio_amd import default_opt, synth\n"
+        "from test_gpu_parity import make_model\n"
+        "opt = default_opt(img_h=72, img_w=136)\n"
+        "model, sd = make_model(opt, seed=22)\n"
+        "img = synth.images(2, 4, 72, 136, seed=6)\n"
+        "fv = model.image_encoder(img.cuda()); model.check()\n"
+        f"torch.save(fv.cpu(), {out!r})\n")
+    env = dict(os.environ, ODEVIO_CONV_OFF64="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    opt = default_opt(img_h=72, img_w=136)
+    model, sd = make_model(opt, seed=22)
+    img = synth.images(2, 4, 72, 136, seed=6)
+    fv64 = torch.load(out, weights_only=True)
+    assert_close(fv64, oc.image_encoder(sd, img), what="fv, 64-bit addressing form")
+    assert torch.equal(fv64, model.image_encoder(img.cuda()).cpu())        # same arithmetic, another address computation
 
 
 def test_image_encoder_golden_full_size(dev, golden_dir):
