@@ -1820,7 +1820,8 @@ extern "C" int odevio_imu_encoder_bwd(odevio_plan* p, const float* imu, int32_t 
   m.eps = 1e-5f;
   m.proj_w = p->proj_w;
   m.i_f_len = p->cfg.i_f_len;
-  if (m.i_f_len % 16) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_imu_encoder_bwd: i_f_len must be a multiple of 16");
+  if (m.i_f_len % 16 || m.i_f_len > 256)   // (the workspace holds the transposed projection as [2816][<= 256])
+    return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_imu_encoder_bwd: i_f_len must be a multiple of 16, at most 256");
   for (int j = 0; j < n_grads; ++j) {
     if (!grads[j].name || !grads[j].data) return fail(ODEVIO_ERR_BAD_ARG, "odevio_imu_encoder_bwd: gradient %d has no name / pointer", j);
     const std::string nm = grads[j].name;
