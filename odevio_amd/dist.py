@@ -5,6 +5,9 @@ src/models/PoseODERNN.py:72-75) and eval-mode BatchNorm - so rank r simply takes
 of the batch with a full weight replica, and nothing is exchanged during compute.  The only
 collective is one all-gather of the per-sequence poses [B/N, S-1, 6] (and of h_T on its batch axis,
 dim 1, when the caller streams) - RCCL over xGMI on the GPUs (backend "nccl"), gloo in the CPU tests.
+Training adds the one real exchange step of data parallelism: the gradients of a step, summed over the ranks in ONE
+bucket (``allreduce_gradients``: Pose_net + Inertial_net are 5.6 M floats = 22 MB - a single RCCL all-reduce per step; xGMI
+rings are per-link bound, so fewer and larger collectives are the right shape).
 The reference itself has no distributed code (single-device nn.DataParallel only).
 """
 import torch
@@ -59,3 +62,22 @@ def forward_sharded(model, img, imu, ts, hc=None, group=None):
         raise ValueError(f"batch {B} is smaller than the world size {world}")
     poses, h_T = model(a, b, c, d)
     return gather_outputs(poses, h_T, B, group)
+
+
+def allreduce_gradients(grads, group=None):
+    """Sum the gradient tensors over the ranks of ``group`` in place, as ONE flat bucket (one all-reduce).
+
+    The caller scales its loss by 1 / world_size before ``backward`` so that the sum is the data-parallel mean - no
+    arithmetic happens here, only packing (copies) around the collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    flat = torch.empty(sum(g.numel() for g in grads), device=grads[0].device, dtype=grads[0].dtype)
+    off = 0
+    for g in grads:
+        flat[off:off + g.numel()].copy_(g.reshape(-1))
+        off += g.numel()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()

@@ -211,8 +211,11 @@ class PoseNetTrainer:
     their backward are not built, and their parameters are not the optimizer's).
     """
 
-    def __init__(self, model, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, gradient_clip=None):
+    def __init__(self, model, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, gradient_clip=None, process_group=None):
         opt = model.opt
+        # data parallel over the GPUs of a node (one process per GPU): every rank steps on its own sequences, the loss is scaled by
+        # 1 / world_size and the gradients are summed in ONE RCCL all-reduce before clip + Adam (odevio_amd.dist.allreduce_gradients)
+        self.process_group = process_group
         if opt.model_type not in ("ode-rnn", "rnn"):
             raise ValueError("PoseNetTrainer: model_type must be ode-rnn or rnn")
         self.model = model
@@ -264,13 +267,16 @@ class PoseNetTrainer:
             grads.append(p.grad.contiguous().float())
         stream = model._stream()
         model._ensure_plan()
+        extra_pairs = [(n, p) for n, p in model.named_parameters() if p.grad is not None and n not in self._name_set]
+        if self._world() > 1:
+            from . import dist as _dist
+            for _, p in extra_pairs:
+                p.grad = p.grad.contiguous().float()
+            _dist.allreduce_gradients(grads + [p.grad for _, p in extra_pairs], self.process_group)
         # clip_grad_norm_(model.parameters()): every parameter that has a gradient counts in the norm - with the recipe's frozen
         # Image_net that is Pose_net (updated below) and Inertial_net (in the norm only: the reference's optimizer does not hold it)
-        extra_names, extra = [], []
-        for n, p in model.named_parameters():
-            if p.grad is not None and n not in self._name_set:
-                extra_names.append(n)
-                extra.append(p.grad.contiguous().float())
+        extra_names = [n for n, _ in extra_pairs]
+        extra = [p.grad.contiguous().float() for _, p in extra_pairs]
         _lib.check(lib.odevio_grad_clip(model._plan, _tensor_array(self.names + extra_names, grads + extra), len(grads) + len(extra),
                                         self.gradient_clip, self.norm_coef.data_ptr(), stream))
         self.steps += 1
@@ -281,6 +287,10 @@ class PoseNetTrainer:
         # the kernels read their own layouts of these parameters (column shards, transposes): refresh them in place
         _lib.check(lib.odevio_plan_update(model._plan, _tensor_array(self.names, [p.detach() for p in self.params]), len(self.params), stream))
         model._plan_sig = model._signature()
+
+    def _world(self):
+        import torch.distributed as tdist
+        return tdist.get_world_size(self.process_group) if (tdist.is_available() and tdist.is_initialized()) else 1
 
     def zero_all_grads(self):
         for p in self.model.parameters():
@@ -297,7 +307,8 @@ class PoseNetTrainer:
             fi = imu_encoder(self.model, imu)
         poses, h_T = pose_net(self.model, fv, fi, timestamps, hc)
         loss = pose_loss(poses, gts)
-        loss.backward()
+        world = self._world()
+        (loss if world == 1 else loss * (1.0 / world)).backward()   # the sum over ranks in apply_gradients is then the mean
         self.apply_gradients()
         self.zero_all_grads()
         return loss.detach(), poses.detach(), h_T.detach()

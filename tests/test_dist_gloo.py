@@ -70,3 +70,41 @@ def test_shard_range_covers_every_sequence_once():
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from odevio_amd import dist as od
+    g = torch.Generator().manual_seed(100 + rank)
+    shapes = [(7, 5), (13,), (3, 4, 2), (1,)]
+    grads = [torch.randn(*s, generator=g) for s in shapes]
+    mine = [x.clone() for x in grads]
+    od.allreduce_gradients(grads)
+    # what every rank must now hold: the sum of all ranks' tensors (each rank can regenerate the others' from their seeds)
+    want = [torch.zeros(*s) for s in shapes]
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        for w, s in zip(want, shapes):
+            w += torch.randn(*s, generator=gr)
+    ok = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(grads, want)) and all(a.shape == b.shape for a, b in zip(grads, mine))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_allreduce_two_ranks():
+    """The training step's one exchange: every gradient tensor summed over the ranks through ONE flat bucket."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
