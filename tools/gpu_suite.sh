@@ -20,5 +20,5 @@ step() {  # name, timeout seconds, command...
 step tests 900 python -m pytest tests -q -m gpu -p no:cacheprovider
 step audit 900 env ODEVIO_LIB=$PWD/odevio_amd/libodevio_audit.so python -m pytest tests -q -m gpu -p no:cacheprovider -k "$KAUDIT"
 step bench 600 python bench.py
-step bench_plain 300 env ODEVIO_PLAIN_LAUNCH=1 python bench.py --no-cpu-baseline --no-f32-reference
+step bench_again 300 python bench.py --no-cpu-baseline --no-f32-reference   # a second line: run-to-run spread on the same box
 exit 0
