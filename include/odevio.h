@@ -183,6 +183,18 @@ int odevio_pose_loss(const float* poses, const float* gts, int32_t n_rows, float
  * call).  The same seed gives the same sequence of masks; plans start at seed 0. */
 int odevio_set_seed(odevio_plan* plan, uint64_t seed);
 
+/* State of the plan's random stream: the seed and the number of draws so far.  The call index a "hard" fusion forward will use is
+ * `calls` read BEFORE it; odevio_fuse_hard_bwd regenerates the same noise from (seed, call). */
+int odevio_rng_state(odevio_plan* plan, uint64_t* seed, uint64_t* calls);
+/* Test hook: the Gumbel(0,1) pair of each of n elements for draw `call` of `seed` -> out [n][2] (device). */
+int odevio_debug_gumbel(uint64_t seed, uint64_t call, int64_t n, float* out, void* stream);
+/* FusionModule "hard" backward (FusionModule.py:24-29): the straight-through estimator of F.gumbel_softmax(..., hard=True) - the
+ * forward value is the one-hot mask, the gradient is y_soft's - for the mask of draw (seed, call).  Gradients of
+ * Pose_net.fuse.net.0.weight [2F,F] / .bias [2F] as named in `grads`. */
+int odevio_fuse_hard_bwd(odevio_plan* plan, const float* fv, const float* fi, int32_t P, uint64_t seed, uint64_t call,
+                         const float* grad_fused, float* grad_fv, float* grad_fi, const odevio_tensor* grads, int32_t n_grads,
+                         void* stream);
+
 /* FusionModule backward (reference src/models/FusionModule.py:17-23; autograd in scripts/train_model.py:78): fv [P,v], fi [P,i],
  * grad_fused [P,v+i] -> grad_fv [P,v], grad_fi [P,i] (either may be NULL) and, for fuse_method "soft", the gradients of
  * Pose_net.fuse.net.0.weight / .bias named in `grads` (device pointers, reference shapes).  ("hard" is not a device

@@ -26,6 +26,7 @@ SYMBOLS = [
     "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func", "odevio_cde_last_ms",
     "odevio_ode_rnn_bwd", "odevio_pose_loss", "odevio_resize_u8", "odevio_resize_table",
     "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update", "odevio_imu_encoder_bwd", "odevio_set_seed",
+    "odevio_rng_state", "odevio_debug_gumbel", "odevio_fuse_hard_bwd",
 ]
 
 
@@ -115,6 +116,10 @@ def load():
     lib.odevio_plan_update.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_imu_encoder_bwd.argtypes = [vp, fp, i32, i32, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_set_seed.argtypes = [vp, ctypes.c_uint64]
+    u64 = ctypes.c_uint64
+    lib.odevio_rng_state.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.odevio_debug_gumbel.argtypes = [u64, u64, ctypes.c_int64, fp, vp]
+    lib.odevio_fuse_hard_bwd.argtypes = [vp, fp, fp, i32, u64, u64, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_resize_table.argtypes = [i32, i32, vp, vp, vp, i32]
     lib.odevio_resize_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp]
     lib.odevio_cde_func.argtypes = [vp, fp, fp, i32, i32, i32, fp, vp]

@@ -390,6 +390,7 @@ static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
   if (p->cfg.fuse_method == ODEVIO_FUSE_HARD) {   // Linear(F, 2F): logits (keep, drop) per feature, interleaved (FusionModule.py:14,26)
     PN(wt.get("Pose_net.fuse.net.0.weight", (int64_t)2 * F * F, w));
     PN(upload(p, &p->fuse_w, w, st));
+    PN(upload(p, &p->fuse_w_t, transposed(w, 2 * F, F), st));   // backward: g_cat += g_logits W
     PN(wt.get("Pose_net.fuse.net.0.bias", (int64_t)2 * F, bias));
     PN(upload(p, &p->fuse_b, bias, st));
   }
@@ -1730,7 +1731,9 @@ extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, 
     copy(p->fuse_b, src("Pose_net.fuse.net.0.bias", F), F);
   }
   if (p->cfg.fuse_method == ODEVIO_FUSE_HARD) {
-    copy(p->fuse_w, src("Pose_net.fuse.net.0.weight", (int64_t)2 * F * F), (size_t)2 * F * F);
+    const float* wh = src("Pose_net.fuse.net.0.weight", (int64_t)2 * F * F);
+    copy(p->fuse_w, wh, (size_t)2 * F * F);
+    relayout_transpose(wh, p->fuse_w_t, 2 * F, F, st);
     copy(p->fuse_b, src("Pose_net.fuse.net.0.bias", (int64_t)2 * F), (size_t)2 * F);
   }
   {
@@ -1774,6 +1777,49 @@ extern "C" int odevio_set_seed(odevio_plan* p, uint64_t seed) {
   ARGCHK(p, "odevio_set_seed: bad argument");
   p->seed = seed;
   p->rng_calls = 0;
+  return 0;
+}
+
+extern "C" int odevio_rng_state(odevio_plan* p, uint64_t* seed, uint64_t* calls) {
+  ARGCHK(p && seed && calls, "odevio_rng_state: bad argument");
+  *seed = p->seed;
+  *calls = p->rng_calls;
+  return 0;
+}
+
+extern "C" int odevio_debug_gumbel(uint64_t seed, uint64_t call, int64_t n, float* out, void* stream) {
+  ARGCHK(out && n > 0, "odevio_debug_gumbel: bad argument");
+  launch_gumbel_dump(out, (size_t)n, seed, call, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? 0 : fail(ODEVIO_ERR_HIP, "odevio_debug_gumbel: launch failed");
+}
+
+// FusionModule "hard": the straight-through backward for the mask drawn by call `call` of seed `seed` (odevio_rng_state before the
+// forward); uses train.hip's skinny GEMMs like the soft path
+extern "C" int odevio_fuse_hard_bwd(odevio_plan* p, const float* fv, const float* fi, int32_t P, uint64_t seed, uint64_t call,
+                                    const float* grad_fused, float* grad_fv, float* grad_fi, const odevio_tensor* grads, int32_t n_grads,
+                                    void* stream) {
+  ARGCHK(p && fv && fi && grad_fused && P > 0 && n_grads >= 0 && (grads || n_grads == 0), "odevio_fuse_hard_bwd: bad argument");
+  if (p->cfg.fuse_method != ODEVIO_FUSE_HARD) return fail(ODEVIO_ERR_BAD_ARG, "odevio_fuse_hard_bwd: the plan's fuse_method is not 'hard'");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  const int F = p->F;
+  float *gW = nullptr, *gb = nullptr;
+  for (int i = 0; i < n_grads; ++i) {
+    if (!grads[i].name || !grads[i].data) return fail(ODEVIO_ERR_BAD_ARG, "odevio_fuse_hard_bwd: gradient %d has no name / pointer", i);
+    const std::string nm = grads[i].name;
+    int64_t want = -1;
+    if (nm == "Pose_net.fuse.net.0.weight") { gW = (float*)grads[i].data; want = (int64_t)2 * F * F; }
+    else if (nm == "Pose_net.fuse.net.0.bias") { gb = (float*)grads[i].data; want = (int64_t)2 * F; }
+    if (want < 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_fuse_hard_bwd: '%s' is not a parameter of this fusion module", nm.c_str());
+    if (want != grads[i].numel) return fail(ODEVIO_ERR_BAD_ARG, "odevio_fuse_hard_bwd: gradient '%s' has the wrong size", nm.c_str());
+  }
+  const size_t n = (size_t)P * F;
+  int rc;
+  if ((rc = ensure(p->train_aux, 6 * n))) return rc;          // cat, logits [2n], g_logits [2n], g_cat
+  float *cat = p->train_aux.p, *logits = cat + n, *gl = logits + 2 * n, *gc = gl + 2 * n;
+  rc = train_fuse_hard_bwd(p->fuse_w, p->fuse_w_t, p->fuse_b, cat, logits, gl, gc, fv, p->cfg.v_f_len, fi, p->cfg.i_f_len, P, seed, call, grad_fused,
+                           grad_fv, grad_fi, gW, gb, st);
+  if (rc) return fail(rc, "odevio_fuse_hard_bwd: %s", hipGetErrorString(hipGetLastError()));
   return 0;
 }
 

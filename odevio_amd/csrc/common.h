@@ -189,3 +189,6 @@ __device__ __forceinline__ float apply_epi(float v, int act, float slope) {
 // fuse_method "hard" (api.hip fuse_from_cat): fused = cat * [logit(2j) + g0 >= logit(2j+1) + g1], Gumbel noise from Philox 4x32-10
 void launch_hard_mask(const float* cat, const float* logits, float* fused, size_t n, unsigned long long seed, unsigned long long call,
                       hipStream_t st);
+void launch_hard_mask_bwd(const float* g, const float* cat, const float* logits, float* g_cat, float* g_logits, size_t n,
+                          unsigned long long seed, unsigned long long call, hipStream_t st);
+void launch_gumbel_dump(float* out, size_t n, unsigned long long seed, unsigned long long call, hipStream_t st);

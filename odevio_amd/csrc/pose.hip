@@ -181,3 +181,52 @@ void launch_hard_mask(const float* cat, const float* logits, float* fused, size_
   const unsigned blocks = (unsigned)std::min<size_t>(((n + 1) / 2 + 255) / 256, 2048);
   hipLaunchKernelGGL(hard_mask_kernel, dim3(blocks), dim3(256), 0, st, cat, logits, fused, n, seed, call);
 }
+
+// Straight-through backward of the hard mask (F.gumbel_softmax(..., hard=True): ret = y_hard - y_soft.detach() + y_soft, so the
+// gradient is y_soft's).  With the same Philox block as the forward: s = sigmoid((l0 + g0) - (l1 + g1)) = y_soft[..., 0];
+//   g_cat (direct part) = g * mask;   g_l0 = g * cat * s (1 - s);   g_l1 = -g_l0      (logits interleaved [P][2F])
+__global__ void hard_mask_bwd_kernel(const float* __restrict__ g, const float* __restrict__ cat, const float* __restrict__ logits,
+                                     float* __restrict__ g_cat, float* __restrict__ g_logits, size_t n, unsigned long long seed,
+                                     unsigned long long call) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n + 1) / 2; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned c[4] = {(unsigned)i, (unsigned)(i >> 32), (unsigned)call, (unsigned)(call >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const size_t j = 2 * i + e;
+      if (j < n) {
+        const float keep = logits[2 * j] + gumbel_from_bits(c[2 * e]), drop = logits[2 * j + 1] + gumbel_from_bits(c[2 * e + 1]);
+        const float sg = 1.0f / (1.0f + expf(drop - keep));
+        const float gj = g[j];
+        g_cat[j] = keep >= drop ? gj : 0.f;
+        const float gl = gj * cat[j] * sg * (1.0f - sg);
+        g_logits[2 * j] = gl;
+        g_logits[2 * j + 1] = -gl;
+      }
+    }
+  }
+}
+void launch_hard_mask_bwd(const float* g, const float* cat, const float* logits, float* g_cat, float* g_logits, size_t n,
+                          unsigned long long seed, unsigned long long call, hipStream_t st) {
+  const unsigned blocks = (unsigned)std::min<size_t>(((n + 1) / 2 + 255) / 256, 2048);
+  hipLaunchKernelGGL(hard_mask_bwd_kernel, dim3(blocks), dim3(256), 0, st, g, cat, logits, g_cat, g_logits, n, seed, call);
+}
+// diagnostic / test hook: the Gumbel pair of every element of call `call` (out [n][2]), what both kernels above draw
+__global__ void gumbel_dump_kernel(float* __restrict__ out, size_t n, unsigned long long seed, unsigned long long call) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n + 1) / 2; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned c[4] = {(unsigned)i, (unsigned)(i >> 32), (unsigned)call, (unsigned)(call >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const size_t j = 2 * i + e;
+      if (j < n) {
+        out[2 * j] = gumbel_from_bits(c[2 * e]);
+        out[2 * j + 1] = gumbel_from_bits(c[2 * e + 1]);
+      }
+    }
+  }
+}
+void launch_gumbel_dump(float* out, size_t n, unsigned long long seed, unsigned long long call, hipStream_t st) {
+  const unsigned blocks = (unsigned)std::min<size_t>(((n + 1) / 2 + 255) / 256, 2048);
+  hipLaunchKernelGGL(gumbel_dump_kernel, dim3(blocks), dim3(256), 0, st, out, n, seed, call);
+}

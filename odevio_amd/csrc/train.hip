@@ -834,3 +834,20 @@ void skinny_linear(const float* A, int lda, const float* W, int ldw, const float
   gemm_nt(st, A, lda, W, ldw, bias, out, ldo, M, N, K);
 }
 void leaky_inplace(float* x, size_t n, float slope, hipStream_t st) { hipLaunchKernelGGL(leaky_kernel, EW_GRID(n), 0, st, x, n, slope); }
+
+// FusionModule "hard" backward: logits = cat W^T + b recomputed, the element-wise part in pose.hip (same Philox block as the forward),
+// then g_W = g_logits^T cat, g_b = column sums, g_cat += g_logits W.
+int train_fuse_hard_bwd(const float* W, const float* W_t, const float* bias, float* cat, float* logits, float* g_logits, float* g_cat,
+                        const float* fv, int nv, const float* fi, int ni, int P, unsigned long long seed, unsigned long long call,
+                        const float* g_fused, float* g_fv, float* g_fi, float* g_W, float* g_b, hipStream_t st) {
+  const int F = nv + ni;
+  const size_t n = (size_t)P * F;
+  hipLaunchKernelGGL(cat_rows_kernel, EW_GRID(n), 0, st, fv, nv, fi, ni, cat, (size_t)P);
+  gemm_nt(st, cat, F, W, F, bias, logits, 2 * F, P, 2 * F, F);
+  launch_hard_mask_bwd(g_fused, cat, logits, g_cat, g_logits, n, seed, call, st);
+  gemm_nt(st, g_logits, 2 * F, W_t, 2 * F, nullptr, g_cat, F, P, F, 2 * F, true);   // g_cat += g_logits W
+  if (g_W) gemm_tn(st, g_logits, 2 * F, cat, F, g_W, F, P, 2 * F, F);
+  if (g_b) hipLaunchKernelGGL(colsum_kernel, EW_GRID(2 * F), 0, st, g_logits, g_b, P, 2 * F);
+  hipLaunchKernelGGL(split_rows_kernel, EW_GRID(n), 0, st, g_cat, g_fv, nv, g_fi, ni, (size_t)P);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}

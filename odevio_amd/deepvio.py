@@ -339,6 +339,13 @@ class DeepVIO(nn.Module):
         self._ensure_plan()
         _lib.check(self._lib.odevio_set_seed(self._plan, int(seed) & 0xFFFFFFFFFFFFFFFF))
 
+    def rng_state(self):
+        """(seed, draws so far) of the plan's random stream: the next "hard" fusion forward uses draw index = the second value."""
+        self._ensure_plan()
+        seed, calls = ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self._lib.odevio_rng_state(self._plan, ctypes.byref(seed), ctypes.byref(calls)))
+        return int(seed.value), int(calls.value)
+
     def fuse(self, fv, fi):
         self._ensure_plan()
         fv, fi = self._dev(fv, "fv"), self._dev(fi, "fi")

@@ -7,7 +7,7 @@ run in libodevio (``odevio_ode_rnn_fwd`` / ``odevio_ode_rnn_bwd``, ``odevio_pose
 
 What ``odevio_ode_rnn_bwd`` covers: fixed-step solvers (rk4, rk4_classic) and adaptive ones (dopri5, tsit5, heun: the
 forward's accepted steps are replayed, their sizes held constant), ``nn.RNN`` and ``nn.GRU``; ``odevio_fuse_bwd`` covers
-``cat`` and ``soft`` fusion.  Gradients reach the encoder FEATURES (fv, fi), the carried state ``hc`` and every parameter
+``cat`` and ``soft`` fusion, ``odevio_fuse_hard_bwd`` the straight-through estimator of ``hard``.  Gradients reach the encoder FEATURES (fv, fi), the carried state ``hc`` and every parameter
 of ``Pose_net`` (fusion, ODEFunc, RNN, regressor) - exactly the parameters the reference's optimizer holds
 (utils/utils.py:115-119: ``Pose_net.get_other_params()`` + ``get_regressor_params()``; the encoders are not in it).
 ``PoseNetTrainer`` is that optimizer step on the device: ``clip_grad_norm_`` + ``torch.optim.Adam`` as kernels
@@ -60,6 +60,7 @@ class _FuseFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, names, fv, fi, *params):
         fv, fi = fv.detach().contiguous().float(), fi.detach().contiguous().float()
+        ctx.rng = model.rng_state() if model.opt.fuse_method == "hard" else None   # the draw this forward's Gumbel mask uses
         fused = model.fuse(fv, fi)
         ctx.model, ctx.names = model, names
         ctx.param_shapes = [tuple(p.shape) for p in params]
@@ -75,8 +76,12 @@ class _FuseFunction(torch.autograd.Function):
         grads = [torch.empty(s, device=fv.device, dtype=torch.float32) for s in ctx.param_shapes]
         arr = _tensor_array(ctx.names, grads)
         model._ensure_plan()
-        _lib.check(model._lib.odevio_fuse_bwd(model._plan, fv.data_ptr(), fi.data_ptr(), fv.shape[0] * fv.shape[1], g_fused.data_ptr(),
-                                              g_fv.data_ptr(), g_fi.data_ptr(), arr, len(grads), model._stream()))
+        if ctx.rng is not None:   # "hard": straight-through gradient for the mask of that draw
+            _lib.check(model._lib.odevio_fuse_hard_bwd(model._plan, fv.data_ptr(), fi.data_ptr(), fv.shape[0] * fv.shape[1], ctx.rng[0], ctx.rng[1],
+                                                       g_fused.data_ptr(), g_fv.data_ptr(), g_fi.data_ptr(), arr, len(grads), model._stream()))
+        else:
+            _lib.check(model._lib.odevio_fuse_bwd(model._plan, fv.data_ptr(), fi.data_ptr(), fv.shape[0] * fv.shape[1], g_fused.data_ptr(),
+                                                  g_fv.data_ptr(), g_fi.data_ptr(), arr, len(grads), model._stream()))
         return (None, None, g_fv, g_fi, *grads)
 
 
@@ -189,8 +194,6 @@ def pose_net(model, fv, fi, timestamps, hc=None):
     opt = model.opt
     if opt.model_type not in ("ode-rnn", "rnn"):
         raise ValueError("odevio_amd.train.pose_net: model_type must be ode-rnn or rnn")
-    if opt.fuse_method not in ("cat", "soft"):
-        raise ValueError("odevio_amd.train.pose_net: fuse_method 'hard' (straight-through Gumbel mask) has no backward here")
     model._ensure_plan()
     names = pose_param_names(opt)
     params = dict(model.named_parameters())

@@ -120,8 +120,6 @@ def test_backward_refuses_what_is_not_built():
     with pytest.raises(ValueError, match="euler"):
         poses.sum().backward()
 
-    with pytest.raises(ValueError, match="hard"):
-        train.pose_net(make_model(default_opt(img_h=64, img_w=128, fuse_method="hard"), seed=1)[0], fv, fi, synth.timestamps(2, 4).cuda())
 
 
 def test_pose_loss_matches_the_reference_formula():
@@ -318,3 +316,51 @@ def test_train_epoch_runs_the_reference_loop_end_to_end():
     model.check()
     assert all(m == m for m in means) and means[-1] < 0.8 * means[0], means
     assert len(lines) == 12 and "pose loss" in lines[0]
+
+
+def test_hard_fusion_straight_through_backward_with_the_same_noise():
+    """FusionModule "hard" in training: F.gumbel_softmax(..., hard=True) returns y_hard - y_soft.detach() + y_soft, so the forward
+    value is the one-hot mask and the gradient is y_soft's.  The reference draws its Gumbel noise from torch's generator; here the
+    oracle is handed the noise the device drew (odevio_debug_gumbel for the same seed and draw index) - with equal noise the mask
+    and every gradient must agree."""
+    import ctypes
+    from odevio_amd import _lib
+    opt = default_opt(img_h=64, img_w=128, fuse_method="hard", model_type="rnn", rnn_num_layers=1)
+    model, sd = make_model(opt, seed=86)
+    B, P, F = 3, 4, 768
+    g = torch.Generator().manual_seed(13)
+    fv, fi = torch.randn(B, P, 512, generator=g), torch.randn(B, P, 256, generator=g)
+    ts = synth.timestamps(B, P + 1, seed=5)
+    gts = torch.randn(B, P, 6, generator=g) * torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    model.set_seed(21)
+    seed, call = model.rng_state()
+    noise = torch.empty(B * P * F, 2, device="cuda")
+    _lib.check(model._lib.odevio_debug_gumbel(seed, call, B * P * F, noise.data_ptr(), model._stream()))
+    noise = noise.cpu().double().reshape(B, P, F, 2)
+    # reference arithmetic (FusionModule.py:24-29 + torch.nn.functional.gumbel_softmax, tau = 1) with that noise, float64
+    names = train.fuse_param_names(opt) + train.pose_param_names(opt)
+    leaves = {k: v.clone().double().requires_grad_(k in names) for k, v in sd.items() if v.is_floating_point()}
+    fv64, fi64 = fv.double().requires_grad_(True), fi.double().requires_grad_(True)
+    cat = torch.cat((fv64, fi64), -1)
+    logits = torch.nn.functional.linear(cat, leaves["Pose_net.fuse.net.0.weight"], leaves["Pose_net.fuse.net.0.bias"]).view(B, P, F, 2)
+    y_soft = (logits + noise).softmax(-1)
+    y_hard = torch.zeros_like(y_soft).scatter_(-1, y_soft.max(-1, keepdim=True)[1], 1.0)
+    ret = y_hard - y_soft.detach() + y_soft
+    fused = cat * ret[..., 0]
+    cat_opt = default_opt(img_h=64, img_w=128, fuse_method="cat", model_type="rnn", rnn_num_layers=1)
+    poses, _ = oc.pose_ode_rnn(leaves, fused[..., :512], fused[..., 512:], ts, None, cat_opt, dtype=torch.float64, with_ode=False)
+    loss = 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3].double()) + torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:].double())
+    loss.backward()
+    # device path, same seed -> same draw
+    model.set_seed(21)
+    fv_d, fi_d = fv.cuda().requires_grad_(True), fi.cuda().requires_grad_(True)
+    poses_d, _ = train.pose_net(model, fv_d, fi_d, ts.cuda())
+    train.pose_loss(poses_d, gts.cuda()).backward()
+    model.check()
+    assert oc.rel_err(poses_d, poses.detach()) < 1e-4                      # same mask, same forward
+    errs = {"fv": oc.rel_err(fv_d.grad, fv64.grad), "fi": oc.rel_err(fi_d.grad, fi64.grad)}
+    params = dict(model.named_parameters())
+    for n in names:
+        errs[n] = oc.rel_err(params[n].grad, leaves[n].grad)
+    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v < GTOL}
+    assert not bad, f"gradients off by more than {GTOL}: {bad}"
