@@ -48,6 +48,10 @@ int main(void) {
   EXPECT(odevio_grad_clip(NULL, NULL, 0, 5.0f, x, NULL) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_adam_step(x, x, x, x, 4, 1e-4f, 0.9f, 0.999f, 1e-8f, 0.0f, 0, NULL, NULL) == ODEVIO_ERR_BAD_ARG);   /* step counts from 1 */
   EXPECT(odevio_plan_update(NULL, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_fuse_hard_bwd(NULL, x, x, 1, 0, 0, x, x, x, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_rng_state(NULL, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_debug_gumbel(0, 0, 0, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_set_seed(NULL, 1) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_resize_u8(NULL, 1, 4, 4, NULL, 2, 2, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   odevio_plan_destroy(NULL);
   /* resize tables: KITTI width and height, an upscale, a degenerate 1-pixel axis; capacity checked */
