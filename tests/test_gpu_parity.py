@@ -101,6 +101,19 @@ def test_every_tile_shape_of_the_fp16x2_kernel(dev, monkeypatch, force):
         assert torch.equal(got, base)
 
 
+@pytest.mark.parametrize("B,S,H,W", [(1, 2, 64, 128), (3, 3, 80, 208), (5, 2, 128, 256), (2, 6, 96, 160), (7, 3, 64, 192), (1, 9, 128, 128)])
+def test_tile_planner_over_many_shapes(dev, B, S, H, W):
+    """The per-layer tile planner decides from (pixels, channels, K-tiles, CUs): batch and image sizes that give every layer a
+    different pixel count - partial last tiles, layers smaller than one round, XCD map on and off, split-K or not - all have to
+    land on the oracle (the planner's own choices, nothing forced)."""
+    opt = default_opt(img_h=H, img_w=W)
+    model, sd = make_model(opt, seed=90 + B)
+    img = synth.images(B, S, H, W, seed=B * 10 + S)
+    fv = model.image_encoder(img.cuda())
+    model.check()
+    assert_close(fv, oc.image_encoder(sd, img), what=f"fv at B={B} S={S} {H}x{W}")
+
+
 def test_two_phase_tile_plan_matches_single_phase(dev, monkeypatch):
     # a layer split between two tile shapes (R full rounds of the chip in one, the remaining pixels in another), at a size
     # where the split falls inside the batch: conv2 of 8 frame pairs = 65,536 pixels; one round of 192 x 128 tiles covers
