@@ -269,6 +269,32 @@ __device__ __forceinline__ void layer(const float* __restrict__ wbase, int NC, i
   }
 }
 
+// The same product for ONE layer whose slice did not fit in LDS, with this wave's weights held in registers for the whole launch
+// (a 16-column x 512 slice is exactly 2 float4 per lane in the column-major map: wave = column, lane = K slice): the layer then
+// reads nothing but its gathered input.  Same arithmetic and summation order as layer<RT>.
+template <int RT>
+__device__ __forceinline__ void layer_reg(const f32x4 (&wreg)[2], int NC, const float* xs, const int (&roff)[RT], int col0, int lane,
+                                          float* out) {
+  if (col0 >= NC) return;
+  f32x2 acc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) acc[r] = (f32x2){0.f, 0.f};
+  xs += 4 * lane;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xs + j * 256 + roff[r]);
+      acc[r] = __builtin_elementwise_fma(wreg[j].lo, x.lo, acc[r]);
+      acc[r] = __builtin_elementwise_fma(wreg[j].hi, x.hi, acc[r]);
+    }
+  float s0[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) s0[r] = acc[r].x + acc[r].y;
+  const float t0 = reduce_rows64<RT>(s0, lane);
+  if (lane < RT) out[col0 * RT + lane] = t0;
+}
+
 // tanh on the owner threads sits on the critical path of every exchange (one or two waves run it while the
 // rest of the workgroup waits), and ocml's tanhf is ~150 dependent instructions.  This form is ~20:
 // |x| < 0.25: odd Taylor polynomial to x^11 (truncation < 2e-9 relative); otherwise 1 - 2/(e^{2|x|} + 1) with the
@@ -393,6 +419,21 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
   }
   __syncthreads();
 
+  // one slice that did not fit in LDS (the greedy carve leaves out the smallest) lives in registers if it has the shape the
+  // column-major map gives one wave in two loads: <= 16 local columns x 512 inputs
+  int lreg = -1;
+  f32x4 wreg[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int l = 0; l < a.nlin; ++l)
+    if (lreg < 0 && a.w_lds_off[l] < 0 && a.dims[l + 1] / INTEG_MEMBERS <= 16 && pad256(a.dims[l]) == 512) lreg = l;
+  if (lreg >= 0) {
+    const int NC = a.dims[lreg + 1] / INTEG_MEMBERS;
+    if (wave < NC) {
+      const float* src = a.w[lreg] + (size_t)cu * NC * 512 + ((size_t)wave * 64 + lane) * 4;
+      wreg[0] = *reinterpret_cast<const f32x4*>(src);
+      wreg[1] = *reinterpret_cast<const f32x4*>(src + (size_t)NC * 256);
+    }
+  }
+
   int off_ode[RT];
 
   // vector field: the owner threads hand in their stage value sv and get k = f(sv) back
@@ -411,6 +452,8 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
       for (int r = 0; r < RT; ++r) off_ode[r] = (r < R ? r : R - 1) * Kp;
       if (a.w_lds_off[l] >= 0)
         layer<RT>(wl + a.w_lds_off[l], NC, Kp, xin, off_ode, 0, xin, off_ode, wave, lane, lay);
+      else if (l == lreg)
+        layer_reg<RT>(wreg, NC, xin, off_ode, wave, lane, lay);
       else
         layer<RT>(a.w[l] + (size_t)cu * NC * Kp, NC, Kp, xin, off_ode, 0, xin, off_ode, wave, lane, lay);
       STAMP_ADD(c.t_layer, sl0);
