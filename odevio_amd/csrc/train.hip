@@ -261,12 +261,27 @@ __global__ void stage_adjoint_kernel(float* __restrict__ lam, float* __restrict_
   }
 }
 // column sums of a [M][N] matrix (bias gradients); one thread per column, rows in order (deterministic)
-__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
-  EW_LOOP(n, N) {
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) s += x[(size_t)m * N + n];
-    out[n] = s;
+// out[n] = sum over the M rows of x[m][n].  One 256-thread block per 32 columns: 8 row groups stride the rows (each thread adds its
+// rows in order), then the 8 partial sums are combined in group order - deterministic, and M (up to intervals x steps x stages x
+// rows of the tape) is walked by 8 x as many threads, 128 bytes per row segment, instead of one thread per column.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  float s = 0.f;
+  if (n < N)
+    for (int m = g; m < M; m += 8) s += x[(size_t)m * N + n];
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0 && n < N) {
+    float t = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][c];
+    out[n] = t;
   }
+}
+static void launch_colsum(hipStream_t st, const float* x, float* out, int M, int N) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, st, x, out, M, N);
 }
 // regressor.2 backward: dhid[m][k] = (sum_n dp[m][n] W2[n][k]) * leaky'(hid[m][k])   (6 outputs: no GEMM needed)
 __global__ void reg2_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ W2, const float* __restrict__ hid,
@@ -468,19 +483,19 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
   if (m.with_ode) {
     for (int l = 0; l < nl; ++l) {
       if (g.ode_w[l]) gemm_tn(st, delta[l], m.dims[l + 1], act[l], m.dims[l], g.ode_w[l], m.dims[l], (int)M, m.dims[l + 1], m.dims[l]);
-      if (g.ode_b[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(m.dims[l + 1]), 0, st, delta[l], g.ode_b[l], (int)M, m.dims[l + 1]);
+      if (g.ode_b[l]) launch_colsum(st, delta[l], g.ode_b[l], (int)M, m.dims[l + 1]);
     }
   }
   for (int l = 0; l < L; ++l) {
     if (g.rnn_wih[l]) gemm_tn(st, rnn_delta[l], GF, rnn_in[l], F, g.rnn_wih[l], F, (int)MB, GF, F);
     if (g.rnn_whh[l]) gemm_tn(st, rnn_delta_h[l], GF, rnn_hp[l], F, g.rnn_whh[l], F, (int)MB, GF, F);
-    if (g.rnn_bih[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(GF), 0, st, rnn_delta[l], g.rnn_bih[l], (int)MB, GF);
-    if (g.rnn_bhh[l]) hipLaunchKernelGGL(colsum_kernel, EW_GRID(GF), 0, st, rnn_delta_h[l], g.rnn_bhh[l], (int)MB, GF);
+    if (g.rnn_bih[l]) launch_colsum(st, rnn_delta[l], g.rnn_bih[l], (int)MB, GF);
+    if (g.rnn_bhh[l]) launch_colsum(st, rnn_delta_h[l], g.rnn_bhh[l], (int)MB, GF);
   }
   if (g.reg_w0) gemm_tn(st, dhid, 128, rnn_out[L - 1], F, g.reg_w0, F, (int)MB, 128, F);
-  if (g.reg_b0) hipLaunchKernelGGL(colsum_kernel, EW_GRID(128), 0, st, dhid, g.reg_b0, (int)MB, 128);
+  if (g.reg_b0) launch_colsum(st, dhid, g.reg_b0, (int)MB, 128);
   if (g.reg_w2) gemm_tn(st, dpo, 6, hid, 128, g.reg_w2, 128, (int)MB, 6, 128);
-  if (g.reg_b2) hipLaunchKernelGGL(colsum_kernel, EW_GRID(6), 0, st, dpo, g.reg_b2, (int)MB, 6);
+  if (g.reg_b2) launch_colsum(st, dpo, g.reg_b2, (int)MB, 6);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
 
@@ -531,7 +546,7 @@ int train_fuse_bwd(int soft, const float* W, const float* W_t, const float* bias
   hipLaunchKernelGGL(soft_gate_bwd_kernel, EW_GRID(n), 0, st, g_fused, c, w, gw, gc, n);
   gemm_nt(st, gw, F, W_t, F, nullptr, gc, F, P, F, F, true);           // gc += gw W   (W_t rows = columns of W)
   if (g_W) gemm_tn(st, gw, F, c, F, g_W, F, P, F, F);                  // g_W[n][k] = sum_m gw[m][n] c[m][k]
-  if (g_b) hipLaunchKernelGGL(colsum_kernel, EW_GRID(F), 0, st, gw, g_b, P, F);
+  if (g_b) launch_colsum(st, gw, g_b, P, F);
   hipLaunchKernelGGL(split_rows_kernel, EW_GRID(n), 0, st, gc, g_fv, nv, g_fi, ni, (size_t)P);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
@@ -806,7 +821,7 @@ int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, 
   hipLaunchKernelGGL(rows_to_ct_kernel, EW_GRID(rows * 256), 0, st, x[3], flat, (size_t)P, 256);
   // ---- proj backward
   if (g.proj_w) gemm_tn(st, g_fi, NF, flat, 2816, g.proj_w, 2816, P, NF, 2816);
-  if (g.proj_b) hipLaunchKernelGGL(colsum_kernel, EW_GRID(NF), 0, st, g_fi, g.proj_b, P, NF);
+  if (g.proj_b) launch_colsum(st, g_fi, g.proj_b, P, NF);
   relayout_transpose(m.proj_w, projT, NF, 2816, st);                                   // [NF][2816] -> [2816][NF]
   gemm_nt(st, g_fi, NF, projT, NF, nullptr, gflat, 2816, P, 2816, NF);                  // g_flat = g_fi W
   hipLaunchKernelGGL(ct_to_rows_kernel, EW_GRID(rows * 256), 0, st, gflat, gy, (size_t)P, 256);
@@ -814,8 +829,8 @@ int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, 
   for (int l = 3; l >= 1; --l) {
     const int Co = C[l], Ci = C[l - 1], ldk = m.ldk[l - 1];
     hipLaunchKernelGGL(bn_leaky_bwd_kernel, EW_GRID(rows * Co), 0, st, gy, x[l], c[l], m.s[l - 1], dz, dzc, D, rows, Co);
-    hipLaunchKernelGGL(colsum_kernel, EW_GRID(Co), 0, st, dzc, dS, (int)rows, Co);
-    hipLaunchKernelGGL(colsum_kernel, EW_GRID(Co), 0, st, dz, dH, (int)rows, Co);
+    launch_colsum(st, dzc, dS, (int)rows, Co);
+    launch_colsum(st, dz, dH, (int)rows, Co);
     hipLaunchKernelGGL(bn_param_grad_kernel, EW_GRID(Co), 0, st, dS, dH, m.s[l - 1], m.var[l - 1], m.mean[l - 1], m.bias[l - 1], m.eps, g.gamma[l - 1],
                        g.beta[l - 1], g.b[l - 1], Co);
     hipLaunchKernelGGL(im2col3_kernel, EW_GRID(rows * ldk), 0, st, x[l - 1], xcol, rows, Ci, ldk);
@@ -847,7 +862,7 @@ int train_fuse_hard_bwd(const float* W, const float* W_t, const float* bias, flo
   launch_hard_mask_bwd(g_fused, cat, logits, g_cat, g_logits, n, seed, call, st);
   gemm_nt(st, g_logits, 2 * F, W_t, 2 * F, nullptr, g_cat, F, P, F, 2 * F, true);   // g_cat += g_logits W
   if (g_W) gemm_tn(st, g_logits, 2 * F, cat, F, g_W, F, P, 2 * F, F);
-  if (g_b) hipLaunchKernelGGL(colsum_kernel, EW_GRID(2 * F), 0, st, g_logits, g_b, P, 2 * F);
+  if (g_b) launch_colsum(st, g_logits, g_b, P, 2 * F);
   hipLaunchKernelGGL(split_rows_kernel, EW_GRID(n), 0, st, g_cat, g_fv, nv, g_fi, ni, (size_t)P);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
