@@ -218,6 +218,22 @@ def test_hard_fusion_is_a_gumbel_argmax_drawn_on_the_device(dev):
     assert torch.isfinite(poses).all() and torch.isfinite(h).all()
 
 
+def test_device_generator_is_philox4x32_10(dev):
+    """The noise fuse_method "hard" draws on the device is Philox 4x32-10 keyed by the plan's seed: bit-equal uniforms, i.e. Gumbel
+    values equal to the oracle's restatement (pinned by the published known-answer vectors, tests/test_oracle_philox.py) up to the
+    rounding of two float logarithms."""
+    import ctypes
+    from odevio_amd import _lib
+    from oracle import philox as ph
+    lib = _lib.load()
+    for seed, call, n in ((0, 0, 1001), (21, 0, 4096), (0x1234567890ABCDEF, 5, 777), (7, (1 << 33) + 2, 64)):
+        out = torch.empty(n, 2, device="cuda")
+        _lib.check(lib.odevio_debug_gumbel(seed, call, n, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        ref = torch.from_numpy(ph.gumbel_pairs(seed, call, n))
+        assert float((out.cpu() - ref).abs().max()) < 2e-5, (seed, call)      # |g| <= 17: a few ulp of the nested logarithms
+
+
 def test_inertial_encoder(dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "inertial_encoder.npz"))
     opt = default_opt(img_h=64, img_w=128)
