@@ -798,6 +798,25 @@ def test_baseline_config1_full_batch(dev):
         assert_close(h[:, b:b + 1], ref_h, what=f"h_T of sequence {b}")
 
 
+def test_large_batch_crosses_the_4gb_and_chunking_boundaries(dev):
+    """48 sequences x 11 frames of 256x512 on one GPU (the per-GPU load of BASELINE configs[3] is 16; three times that here): conv1's
+    output is 4.03 GB, so conv2 takes the 64-bit DMA addressing form in production conditions (no environment variable), the tile
+    planner sees three times the pixels, and the integrator walks the batch in two launches (32 sequences at 8 rows per group,
+    then 16 at 4).  The oracle checks the first, the 33rd (first of the second launch) and the last sequence."""
+    opt = default_opt(ode_solver="rk4")
+    model, sd = make_model(opt, seed=95, randomize=False)
+    B = 48
+    img, imu, ts = synth.batch(B, 11, 256, 512, drop=0.2, seed=33)
+    poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    assert poses.shape == (B, 10, 6) and h.shape == (2, B, 768)
+    assert torch.isfinite(poses).all() and torch.isfinite(h).all()
+    for b in (0, 32, B - 1):
+        ref_p, ref_h = oc.deepvio_forward(sd, img[b:b + 1], imu[b:b + 1], ts[b:b + 1], None, opt)
+        assert_close(poses[b:b + 1], ref_p, what=f"poses of sequence {b}")
+        assert_close(h[:, b:b + 1], ref_h, what=f"h_T of sequence {b}")
+
+
 def test_encoder_error_against_fp64_truth(dev, monkeypatch, capsys):
     """How far the image encoder (conv1..conv6 + visual head, 256x512) is from an fp64 evaluation of the same network,
     for both arithmetic modes.  The fp16x2 operand split must be as accurate as the fp32-input MFMA path (DESIGN.md 5.1;
