@@ -99,15 +99,24 @@ def inertial_encoder(sd, imu, dtype=torch.float32):
     return out.reshape(B, n_pairs, -1)
 
 
-def fuse(sd, fv, fi, method, dtype=torch.float32):
-    """FusionModule.py:17-23.  ``hard`` is stochastic (Gumbel) and has no parity claim."""
+def fuse(sd, fv, fi, method, dtype=torch.float32, noise=None):
+    """FusionModule.py:17-29.  ``hard`` is stochastic in the reference (F.gumbel_softmax under torch's generator): it is restated
+    here for GIVEN Gumbel noise ``noise`` [..., F, 2] - torch.nn.functional.gumbel_softmax(logits, tau=1, hard=True) with its
+    ``-empty_like(logits).exponential_().log()`` replaced by the argument: y_soft = softmax(logits + noise),
+    ret = y_hard - y_soft.detach() + y_soft (straight-through), fused = cat * ret[..., 0]."""
     sd = _sd(sd, dtype)
     c = torch.cat((fv.to(dtype), fi.to(dtype)), -1)
     if method == "cat":
         return c
     if method == "soft":
         return c * F_.linear(c, sd["Pose_net.fuse.net.0.weight"], sd["Pose_net.fuse.net.0.bias"])
-    raise ValueError(f"fuse method {method!r} has no deterministic restatement")
+    if method == "hard" and noise is not None:
+        logits = F_.linear(c, sd["Pose_net.fuse.net.0.weight"], sd["Pose_net.fuse.net.0.bias"]).view(*c.shape, 2)
+        y_soft = (logits + noise.to(dtype)).softmax(-1)
+        y_hard = torch.zeros_like(y_soft).scatter_(-1, y_soft.max(-1, keepdim=True)[1], 1.0)
+        ret = y_hard - y_soft.detach() + y_soft
+        return c * ret[..., 0]
+    raise ValueError(f"fuse method {method!r} has no deterministic restatement (hard needs the noise)")
 
 
 # ----------------------------------------------------------------------------------------------

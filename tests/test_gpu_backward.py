@@ -341,12 +341,7 @@ def test_hard_fusion_straight_through_backward_with_the_same_noise():
     names = train.fuse_param_names(opt) + train.pose_param_names(opt)
     leaves = {k: v.clone().double().requires_grad_(k in names) for k, v in sd.items() if v.is_floating_point()}
     fv64, fi64 = fv.double().requires_grad_(True), fi.double().requires_grad_(True)
-    cat = torch.cat((fv64, fi64), -1)
-    logits = torch.nn.functional.linear(cat, leaves["Pose_net.fuse.net.0.weight"], leaves["Pose_net.fuse.net.0.bias"]).view(B, P, F, 2)
-    y_soft = (logits + noise).softmax(-1)
-    y_hard = torch.zeros_like(y_soft).scatter_(-1, y_soft.max(-1, keepdim=True)[1], 1.0)
-    ret = y_hard - y_soft.detach() + y_soft
-    fused = cat * ret[..., 0]
+    fused = oc.fuse(leaves, fv64, fi64, "hard", dtype=torch.float64, noise=noise)
     cat_opt = default_opt(img_h=64, img_w=128, fuse_method="cat", model_type="rnn", rnn_num_layers=1)
     poses, _ = oc.pose_ode_rnn(leaves, fused[..., :512], fused[..., 512:], ts, None, cat_opt, dtype=torch.float64, with_ode=False)
     loss = 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3].double()) + torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:].double())
