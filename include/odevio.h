@@ -186,6 +186,10 @@ int odevio_set_seed(odevio_plan* plan, uint64_t seed);
 /* State of the plan's random stream: the seed and the number of draws so far.  The call index a "hard" fusion forward will use is
  * `calls` read BEFORE it; odevio_fuse_hard_bwd regenerates the same noise from (seed, call). */
 int odevio_rng_state(odevio_plan* plan, uint64_t* seed, uint64_t* calls);
+/* Restores a state read with odevio_rng_state - a caller that rebuilds its plan (new weights after load_state_dict or an
+ * optimizer step: odevio_amd.DeepVIO._ensure_plan) carries the stream over, so that every forward keeps drawing FRESH noise
+ * like the reference's F.gumbel_softmax under torch's generator (FusionModule.py:27) instead of replaying draw 0. */
+int odevio_set_rng_state(odevio_plan* plan, uint64_t seed, uint64_t calls);
 /* Test hook: the Gumbel(0,1) pair of each of n elements for draw `call` of `seed` -> out [n][2] (device). */
 int odevio_debug_gumbel(uint64_t seed, uint64_t call, int64_t n, float* out, void* stream);
 /* FusionModule "hard" backward (FusionModule.py:24-29): the straight-through estimator of F.gumbel_softmax(..., hard=True) - the

@@ -26,7 +26,7 @@ SYMBOLS = [
     "odevio_path_accu", "odevio_forward_u8", "odevio_audit_violations", "odevio_cde_func", "odevio_cde_last_ms",
     "odevio_ode_rnn_bwd", "odevio_pose_loss", "odevio_resize_u8", "odevio_resize_table",
     "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update", "odevio_imu_encoder_bwd", "odevio_set_seed",
-    "odevio_rng_state", "odevio_debug_gumbel", "odevio_fuse_hard_bwd",
+    "odevio_rng_state", "odevio_debug_gumbel", "odevio_fuse_hard_bwd", "odevio_set_rng_state",
 ]
 
 
@@ -118,6 +118,7 @@ def load():
     lib.odevio_set_seed.argtypes = [vp, ctypes.c_uint64]
     u64 = ctypes.c_uint64
     lib.odevio_rng_state.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.odevio_set_rng_state.argtypes = [vp, u64, u64]
     lib.odevio_debug_gumbel.argtypes = [u64, u64, ctypes.c_int64, fp, vp]
     lib.odevio_fuse_hard_bwd.argtypes = [vp, fp, fp, i32, u64, u64, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_resize_table.argtypes = [i32, i32, vp, vp, vp, i32]

@@ -71,7 +71,15 @@ struct DevBuf {
 struct odevio_plan {
   odevio_config cfg;
   int device = 0, n_cu = 0;
-  int F = 0;
+  int F = 0;               // v_f_len + i_f_len: the width of every feature / state tensor at the boundary
+  // The persistent integrator shards columns over INTEG_MEMBERS workgroups, so INSIDE it the state and the ODEFunc's hidden
+  // width are rounded up to a multiple of that (Fi, dims[]) with zero weight rows / columns and zero biases - exact: a padded
+  // state element starts at 0, its derivative is tanh(0) = 0, its RNN / GRU update is 0; a padded hidden unit (softplus(0) != 0)
+  // feeds zero columns.  The reference's own shapes (v_f_len = i_f_len = 200, ode_hidden_dim = 200: scripts/run_training.sh:57-70)
+  // need it; for the default shapes Fi == F and nothing changes.
+  int Fi = 0;
+  int dims_real[INTEG_MAX_LIN + 1] = {};
+  bool padded = false;
   // encoder
   float* conv_w[9] = {};
   void* conv_ws[9] = {};   // conv2..conv6 weights as two fp16 pieces (conv_f16x2.hip), [Cout][K-tile][2][32], pre-scaled
@@ -279,6 +287,7 @@ static float split_conv_weights(const std::vector<float>& w, int cout, int cin, 
 // The K axis is given as segments (each padded with zeros to a multiple of 256 = 64 lanes x 4 floats): lane l of
 // a wave multiplies inputs 256j + 4l .. 4l+3 of chunk j, so its weights for (chunk, column) are one float4.
 static int pad256(int k) { return (k + 255) & ~255; }
+static int pad_members(int n) { return (n + INTEG_MEMBERS - 1) / INTEG_MEMBERS * INTEG_MEMBERS; }
 static void shard_columns(const std::vector<float>& W, int N, const std::vector<int>& segs, std::vector<float>& out) {
   const int NC = N / INTEG_MEMBERS;
   int K = 0, Kp = 0;
@@ -339,13 +348,14 @@ static int validate(const odevio_config& c) {
     // applied, reference PoseCDE.py:53-61,83-84,96)
     if (c.cde_hidden_dim != c.v_f_len + c.i_f_len)
       return fail(ODEVIO_ERR_UNSUPPORTED, "cde_hidden_dim (%d) must equal v_f_len + i_f_len (%d)", c.cde_hidden_dim, c.v_f_len + c.i_f_len);
-    if (c.cde_hidden_dim % 32 || c.cde_fn_num_layers < 1 || c.cde_fn_num_layers + 1 > CDE_MAX_LIN)
-      return fail(ODEVIO_ERR_UNSUPPORTED, "cde_hidden_dim must be a multiple of 32 and cde_fn_num_layers in 1..%d", CDE_MAX_LIN - 1);
+    // (hidden sizes other than 128 / 256 / 512 / 1024 run on the generic last-layer kernel: e.g. the reference's own CDE recipe,
+    // v_f_len = i_f_len = 200, cde_hidden_dim = 400, scripts/run_training.sh:57-70)
+    if (c.cde_hidden_dim % 16 || c.cde_fn_num_layers < 1 || c.cde_fn_num_layers + 1 > CDE_MAX_LIN)
+      return fail(ODEVIO_ERR_UNSUPPORTED, "cde_hidden_dim must be a multiple of 16 and cde_fn_num_layers in 1..%d", CDE_MAX_LIN - 1);
     if (c.cde_activation < 0 || c.cde_activation > 3) return fail(ODEVIO_ERR_BAD_ARG, "Activation function not supported");
     if (c.cde_solver != ODEVIO_DOPRI5 && c.cde_solver != ODEVIO_RK4 && c.cde_solver != ODEVIO_EULER)
       return fail(ODEVIO_ERR_BAD_ARG, "Solver not supported");
-    if (c.fuse_method != ODEVIO_FUSE_CAT && c.fuse_method != ODEVIO_FUSE_SOFT)
-      return fail(ODEVIO_ERR_UNSUPPORTED, "fuse method %d is not supported on the Neural-CDE path", c.fuse_method);
+    if (c.fuse_method < ODEVIO_FUSE_CAT || c.fuse_method > ODEVIO_FUSE_HARD) return fail(ODEVIO_ERR_BAD_ARG, "Fusion method not supported");
     if (c.img_h < 64 || c.img_w < 64) return fail(ODEVIO_ERR_BAD_ARG, "image size %dx%d too small", c.img_h, c.img_w);
     if (c.v_f_len % 4 || c.i_f_len % 4) return fail(ODEVIO_ERR_UNSUPPORTED, "feature lengths must be multiples of 4");
     return 0;
@@ -360,10 +370,9 @@ static int validate(const odevio_config& c) {
   if (c.ode_fn_num_layers < 1 || c.ode_fn_num_layers + 1 > INTEG_MAX_LIN)
     return fail(ODEVIO_ERR_UNSUPPORTED, "ode_fn_num_layers must be 1..%d", INTEG_MAX_LIN - 1);
   const int F = c.v_f_len + c.i_f_len;
-  if (F % 64 || F > INTEG_KMAX || c.ode_hidden_dim % 64 || c.ode_hidden_dim > INTEG_KMAX)
-    return fail(ODEVIO_ERR_UNSUPPORTED, "v_f_len+i_f_len (%d) and ode_hidden_dim (%d) must be multiples of 64, at most %d",
-                F, c.ode_hidden_dim, INTEG_KMAX);
-  if (c.v_f_len % 4 || c.i_f_len % 4) return fail(ODEVIO_ERR_UNSUPPORTED, "feature lengths must be multiples of 4");
+  if (c.v_f_len < 4 || c.i_f_len < 4 || c.v_f_len % 4 || c.i_f_len % 4) return fail(ODEVIO_ERR_UNSUPPORTED, "feature lengths must be multiples of 4");
+  if (c.ode_hidden_dim < 1 || F > INTEG_KMAX || c.ode_hidden_dim > INTEG_KMAX)   // (other widths are zero-padded to a multiple of 32 inside the integrator)
+    return fail(ODEVIO_ERR_UNSUPPORTED, "v_f_len+i_f_len (%d) and ode_hidden_dim (%d) must be at most %d", F, c.ode_hidden_dim, INTEG_KMAX);
   if (c.ode_substeps < 1) return fail(ODEVIO_ERR_BAD_ARG, "ode_substeps must be >= 1");
   return 0;
 }
@@ -410,14 +419,22 @@ static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
   // ---- ODEFunc (column-sharded)
   if (p->cfg.model_type == ODEVIO_MODEL_ODE_RNN) {
     p->nlin = p->cfg.ode_fn_num_layers + 1;
-    p->dims[0] = F;
-    for (int l = 1; l < p->nlin; ++l) p->dims[l] = p->cfg.ode_hidden_dim;
-    p->dims[p->nlin] = F;
+    p->dims_real[0] = F;
+    for (int l = 1; l < p->nlin; ++l) p->dims_real[l] = p->cfg.ode_hidden_dim;
+    p->dims_real[p->nlin] = F;
+    for (int l = 0; l <= p->nlin; ++l) p->dims[l] = pad_members(p->dims_real[l]);
     for (int l = 0; l < p->nlin; ++l) {
       const std::string pre = "Pose_net.ode_func.net." + std::to_string(2 * l);
-      const int N = p->dims[l + 1], K = p->dims[l];
+      const int N = p->dims_real[l + 1], K = p->dims_real[l];
+      const int Ni = p->dims[l + 1], Ki = p->dims[l];
       PN(wt.get(pre + ".weight", (int64_t)N * K, w));
-      shard_columns(w, N, {K}, t);
+      if (Ni != N || Ki != K) {
+        std::vector<float> wp((size_t)Ni * Ki, 0.f);
+        for (int n = 0; n < N; ++n) memcpy(&wp[(size_t)n * Ki], &w[(size_t)n * K], K * sizeof(float));
+        shard_columns(wp, Ni, {Ki}, t);
+      } else {
+        shard_columns(w, N, {K}, t);
+      }
       PN(upload(p, &p->ode_w[l], t, st));
       {
         float *pw = const_cast<float*>(p->train.ode_w[l]), *pwt = const_cast<float*>(p->train.ode_w_t[l]);
@@ -427,6 +444,7 @@ static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
         p->train.ode_w_t[l] = pwt;
       }
       PN(wt.get(pre + ".bias", N, bias));
+      bias.resize(Ni, 0.f);
       PN(upload(p, &p->ode_b[l], bias, st));
     }
   }
@@ -437,7 +455,8 @@ static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
     const int gates = gru ? 3 : 1;
     const int V = gru ? 4 : 1;
     p->rnn_vcols = V;
-    const int NCF = F / INTEG_MEMBERS;
+    const int Fi = p->Fi;
+    const int NCF = Fi / INTEG_MEMBERS;
     std::vector<float> wih, whh, bih, bhh;
     for (int l = 0; l < L; ++l) {
       const std::string s = std::to_string(l);
@@ -457,12 +476,13 @@ static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
         p->train.rnn_wih[l] = a; p->train.rnn_wih_t[l] = at; p->train.rnn_whh[l] = b2; p->train.rnn_whh_t[l] = bt;
         p->train.rnn_bih[l] = c; p->train.rnn_bhh[l] = d;
       }
-      // virtual matrix [V*F][2F], row order: member-major, then v, then local unit
-      std::vector<float> vm((size_t)V * F * 2 * F, 0.f), vb((size_t)V * F, 0.f);
+      // virtual matrix [V*Fi][2F], row order: member-major, then v, then local unit (units F .. Fi-1 are padding: zero rows)
+      std::vector<float> vm((size_t)V * Fi * 2 * F, 0.f), vb((size_t)V * Fi, 0.f);
       for (int m = 0; m < INTEG_MEMBERS; ++m)
         for (int v = 0; v < V; ++v)
           for (int ul = 0; ul < NCF; ++ul) {
             const int u = m * NCF + ul;
+            if (u >= F) continue;
             float* dst = &vm[((size_t)(m * V + v) * NCF + ul) * 2 * F];
             if (!gru) {
               memcpy(dst, &wih[(size_t)u * F], F * sizeof(float));
@@ -471,16 +491,16 @@ static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
             } else if (v < 2) {  // r, z
               memcpy(dst, &wih[((size_t)v * F + u) * F], F * sizeof(float));
               memcpy(dst + F, &whh[((size_t)v * F + u) * F], F * sizeof(float));
-              vb[(size_t)v * F + u] = bih[(size_t)v * F + u] + bhh[(size_t)v * F + u];
+              vb[(size_t)v * Fi + u] = bih[(size_t)v * F + u] + bhh[(size_t)v * F + u];
             } else if (v == 2) {  // n, input part
               memcpy(dst, &wih[((size_t)2 * F + u) * F], F * sizeof(float));
-              vb[(size_t)2 * F + u] = bih[(size_t)2 * F + u];
+              vb[(size_t)2 * Fi + u] = bih[(size_t)2 * F + u];
             } else {  // n, hidden part
               memcpy(dst + F, &whh[((size_t)2 * F + u) * F], F * sizeof(float));
-              vb[(size_t)3 * F + u] = bhh[(size_t)2 * F + u];
+              vb[(size_t)3 * Fi + u] = bhh[(size_t)2 * F + u];
             }
           }
-      shard_columns(vm, V * F, {F, F}, t);
+      shard_columns(vm, V * Fi, {F, F}, t);
       PN(upload(p, &p->rnn_w[l], t, st));
       PN(upload(p, &p->rnn_b[l], vb, st));
     }
@@ -505,6 +525,9 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
   p->n_cu = prop.multiProcessorCount;
   const int F = cfg->v_f_len + cfg->i_f_len;
   p->F = F;
+  p->Fi = pad_members(F);
+  p->padded = cfg->model_type != ODEVIO_MODEL_CDE &&
+              (p->Fi != F || (cfg->model_type == ODEVIO_MODEL_ODE_RNN && pad_members(cfg->ode_hidden_dim) != cfg->ode_hidden_dim));
   WeightTable wt;
   wt.st = st;
   for (int i = 0; i < n_weights; ++i)
@@ -1129,9 +1152,16 @@ static int fuse_from_cat(odevio_plan* p, const float* fcat, int P, float* fused,
     // forward value of F.gumbel_softmax(..., tau=1, hard=True)[..., 0] (FusionModule.py:24-29; argmax takes index 0 on a tie)
     int rc = ensure(p->train_aux, (size_t)P * 2 * F);
     if (rc) return rc;
-    if ((rc = run_gemm(p, fcat, P, F, p->fuse_w, 2 * F, nullptr, p->fuse_b, nullptr, 0, p->train_aux.p, 2 * F, EPI_NONE, 0.f, st))) return rc;
+    // (the same skinny fp32-MFMA GEMM as odevio_fuse_hard_bwd's recomputation: forward and backward see the same logit bits, so
+    // the straight-through gradient can never land on a mask the forward did not apply)
+    skinny_linear(fcat, F, p->fuse_w, F, p->fuse_b, p->train_aux.p, 2 * F, P, 2 * F, F, st);
     launch_hard_mask(fcat, p->train_aux.p, fused, (size_t)P * F, p->seed, p->rng_calls++, st);
     return hipGetLastError() == hipSuccess ? 0 : fail(ODEVIO_ERR_HIP, "hard fusion: launch failed");
+  }
+  if (F % 32) {   // the implicit-GEMM kernel walks K in 32-wide tiles; other widths (the reference's 200 + 200) take the skinny GEMM
+    skinny_linear(fcat, F, p->fuse_w, F, p->fuse_b, fused, F, P, F, F, st);
+    mul_inplace(fused, fcat, (size_t)P * F, st);
+    return hipGetLastError() == hipSuccess ? 0 : fail(ODEVIO_ERR_HIP, "soft fusion: launch failed");
   }
   return run_gemm(p, fcat, P, F, p->fuse_w, F, nullptr, p->fuse_b, fcat, F, fused, F, EPI_NONE, 0.f, st);
 }
@@ -1205,7 +1235,7 @@ static bool is_fixed_step(int solver) { return solver == ODEVIO_RK4 || solver ==
 static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int substeps, size_t* lds_bytes) {
   const odevio_config& c = p->cfg;
   memset(&a, 0, sizeof(a));
-  a.F = p->F; a.H = c.ode_hidden_dim; a.nlin = p->nlin; a.act = c.ode_activation;
+  a.F = p->Fi; a.Fio = p->F; a.H = pad_members(c.ode_hidden_dim); a.nlin = p->nlin; a.act = c.ode_activation;
   for (int l = 0; l <= p->nlin; ++l) a.dims[l] = p->dims[l];
   for (int l = 0; l < p->nlin; ++l) { a.w[l] = p->ode_w[l]; a.b[l] = p->ode_b[l]; a.w_lds_off[l] = -1; }
   a.rnn_type = c.rnn_type; a.L = c.rnn_num_layers; a.rnn_vcols = p->rnn_vcols;
@@ -1305,7 +1335,7 @@ static int regress(odevio_plan* p, const float* seq, int M, float* poses, hipStr
   int rc;
   if ((rc = ensure(p->reg_hid, (size_t)M * 128))) return rc;
   static const bool old_gemm = getenv("ODEVIO_REGRESSOR_IGEMM") != nullptr;   // diagnostic: the implicit-GEMM kernel with split-K (0.057 ms)
-  if (!old_gemm && p->F % 16 == 0) {
+  if (!old_gemm || p->F % 32) {
     // Linear(F, 128) + LeakyReLU(0.1) + Linear(128, 6) (PoseODERNN.py:64-67) on the skinny fp32-MFMA GEMM: M is B * (S - 1) rows,
     // three short launches behind the integrator on the critical path
     skinny_linear(seq, p->F, p->reg_w0, p->F, p->reg_b0, p->reg_hid.p, 128, M, 128, p->F, st);
@@ -1584,6 +1614,9 @@ extern "C" int odevio_cde_fwd(odevio_plan* p, const float* obs, int32_t B, int32
 static int fill_train_model(odevio_plan* p, TrainModel& m) {
   const odevio_config& c = p->cfg;
   if (c.model_type == ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "backward: the Neural-CDE path has no backward yet");
+  if (p->padded || p->F % 16 || (c.model_type == ODEVIO_MODEL_ODE_RNN && c.ode_hidden_dim % 16))
+    return fail(ODEVIO_ERR_UNSUPPORTED, "backward: v_f_len+i_f_len (%d) and ode_hidden_dim (%d) must be multiples of 32 (the forward pads other widths)",
+                p->F, c.ode_hidden_dim);
   m = p->train;
   m.gru = c.rnn_type == ODEVIO_RNN_GRU;
   m.F = p->F; m.H = c.ode_hidden_dim; m.L = c.rnn_num_layers; m.act = c.ode_activation;
@@ -1684,6 +1717,7 @@ extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const floa
 extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, int32_t n_weights, void* stream) {
   ARGCHK(p && weights && n_weights > 0, "odevio_plan_update: bad argument");
   if (p->cfg.model_type == ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_plan_update: ode-rnn / rnn plans only");
+  if (p->padded) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_plan_update: widths that are not multiples of 32 need odevio_plan_create");
   hipStream_t st = (hipStream_t)stream;
   POLL(p, st);
   std::map<std::string, std::pair<const float*, int64_t>> m;
@@ -1777,6 +1811,13 @@ extern "C" int odevio_set_seed(odevio_plan* p, uint64_t seed) {
   ARGCHK(p, "odevio_set_seed: bad argument");
   p->seed = seed;
   p->rng_calls = 0;
+  return 0;
+}
+
+extern "C" int odevio_set_rng_state(odevio_plan* p, uint64_t seed, uint64_t calls) {
+  ARGCHK(p, "odevio_set_rng_state: bad argument");
+  p->seed = seed;
+  p->rng_calls = calls;
   return 0;
 }
 

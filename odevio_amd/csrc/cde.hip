@@ -671,10 +671,10 @@ void cde_launch_hidden(const CdeWhen& wh, const float* x, const float* W, const 
 template <int H, bool BF16>
 static hipError_t launch_stream_t(const CdeModel& m, const CdeWhen& wh, const float* x, const float* obs, int B, int L, float* out, hipStream_t st) {
   static unsigned long long attr_mask = 0;
-  if (first_use_on_device(attr_mask)) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cde_stream_kernel<H, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
-    if (e != hipSuccess) return e;
-  }
+  const hipError_t e = once_per_device(attr_mask, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(cde_stream_kernel<H, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
+  });
+  if (e != hipSuccess) return e;
   const int grid = std::min(m.n_cu > 0 ? m.n_cu : 256, H);
   const void* W = BF16 ? m.w_last16 : (const void*)m.w[m.n_hidden];
   hipLaunchKernelGGL((cde_stream_kernel<H, BF16>), dim3(grid), dim3(256), CS_LDS, st, wh, x, W, m.b[m.n_hidden], obs, out, B, L, m.C);
@@ -704,8 +704,9 @@ int cde_launch_last(const CdeModel& m, const CdeWhen& wh, const float* x, const 
   } else {
     const size_t lds = ((size_t)CDE_BT * (H + 8) + CDE_BT * 4) * sizeof(float);
     static unsigned long long attr_mask = 0;
-    if (first_use_on_device(attr_mask))
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(cde_last_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    e = once_per_device(attr_mask, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(cde_last_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    });
     if (e == hipSuccess) hipLaunchKernelGGL(cde_last_generic_kernel, dim3(H), dim3(256), lds, st, wh, x, W, bias, obs, out, B, H, C, L);
   }
   return e == hipSuccess ? 0 : ODEVIO_ERR_HIP;

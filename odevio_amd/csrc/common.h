@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -132,15 +134,24 @@ struct ImuArgs {
   int B, T, pairs_per_seq;
 };
 
-// hipFuncSetAttribute (dynamic LDS beyond 64 KB) is per device: true the first time the calling site runs on the
-// current device (one mask per call site)
-inline bool first_use_on_device(unsigned long long& mask) {
+// hipFuncSetAttribute (dynamic LDS beyond 64 KB) is per device.
+// Runs `fn` (a hipFuncSetAttribute sequence) the first time the calling site is used on the current device; one mask per call
+// site.  Two host threads may create plans / launch at once: the per-process masks are guarded by one mutex, held while `fn` runs,
+// so a second thread never launches before the attribute is set.
+inline std::mutex& launch_once_mutex() {
+  static std::mutex m;
+  return m;
+}
+template <class Fn>
+inline hipError_t once_per_device(unsigned long long& mask, Fn fn) {
+  std::lock_guard<std::mutex> guard(launch_once_mutex());
   int d = 0;
   (void)hipGetDevice(&d);
   const unsigned long long bit = 1ull << (d & 63);
-  const bool first = !(mask & bit);
-  mask |= bit;
-  return first;
+  if (mask & bit) return hipSuccess;
+  const hipError_t e = fn();
+  if (e == hipSuccess) mask |= bit;
+  return e;
 }
 
 void launch_conv_igemm(const ConvArgs& a, hipStream_t st);

@@ -531,12 +531,14 @@ hipError_t launch_conv1_f16x2(const Conv1Args& a, int n_cu, hipStream_t st) {
       a.out_bytes < (size_t)a.B * (a.S - 1) * a.Ho * a.Wo * 256 || !a.planes || !a.zeros || !a.wt16 || !a.out)
     return hipErrorInvalidValue;
   static unsigned long long attr_mask = 0;
-  if (first_use_on_device(attr_mask)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H1_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
+  {
+    const hipError_t e = once_per_device(attr_mask, [] {
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H1_LDS);
+      if (e2 != hipSuccess) return e2;
+      e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
+      if (e2 != hipSuccess) return e2;
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x2_g2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, H1G_LDS);
+    });
     if (e != hipSuccess) return e;
   }
   (void)hipGetLastError();

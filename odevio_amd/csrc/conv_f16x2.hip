@@ -502,11 +502,11 @@ template <int TERMS, int BN, bool O32, int BM>
 static hipError_t launch_tile_o(const ConvSplitArgs& a, dim3 grid, hipStream_t st) {
   static unsigned long long attr_mask = 0;   // the dynamic-LDS attribute is per device
   constexpr int lds_bytes = HTile<BN, BM>::LDS;
-  if (first_use_on_device(attr_mask)) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<TERMS, BN, O32, BM>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) return e;
-  }
+  const hipError_t e = once_per_device(attr_mask, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x2_kernel<TERMS, BN, O32, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               lds_bytes);
+  });
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((conv_f16x2_kernel<TERMS, BN, O32, BM>), grid, dim3(512), lds_bytes, st, a);
   return hipSuccess;
 }
@@ -519,7 +519,8 @@ static hipError_t launch_tile(const ConvSplitArgs& a, dim3 grid, hipStream_t st)
 // Host-side check of what the kernel and its grid assume, at every launch (cheap; the kernel's DMAs are not
 // bounds-checked): layout divisibility, buffer extents, the zero page.
 static bool conv_args_consistent(const ConvSplitArgs& a) {
-  if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || a.KH < 1 || a.KW < 1 || a.stride < 1) return false;
+  // (an fp32 output - the visual head - only needs whole 4-channel vectors: v_f_len = 200 of the reference's own recipes)
+  if (a.Cin % 32 || a.Cout % (a.out_split ? 32 : 4) || a.M <= 0 || a.KH < 1 || a.KW < 1 || a.stride < 1) return false;
   if (a.wide && a.Cout % 256) return false;
   if (a.bm != 256 && !(a.bm == 192 && a.off32)) return false;
   if (a.m_begin < 0 || a.m_begin >= a.m_end || a.m_end > a.M) return false;

@@ -451,8 +451,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
 void launch_conv1(const Conv1Args& a, int n_cu, hipStream_t st) {
   const size_t lds = (size_t)(294 * 64 + 2 * C1_PATCH) * sizeof(float);  // 144,816 B
   static unsigned long long attr_mask = 0;   // per device
-  if (first_use_on_device(attr_mask))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)once_per_device(attr_mask, [&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
   int grid = n_cu < a.n_tiles ? n_cu : a.n_tiles;
   hipLaunchKernelGGL(conv1_kernel, dim3(grid), dim3(256), lds, st, a);
 }

@@ -24,8 +24,9 @@ struct IntegTableau {
 
 struct IntegArgs {
   // ---- vector field  f(y) = tanh(W_n act(... act(W_1 y + b_1)) + b_n)
-  int F, H, nlin, act;
-  int dims[INTEG_MAX_LIN + 1];            // F, H, ..., H, F
+  int F, H, nlin, act;                    // F: INTERNAL state width, a multiple of INTEG_MEMBERS (zero-padded weights, exact)
+  int Fio;                                // width AND row stride of every [.., F] tensor in global memory (<= F): the caller's F
+  int dims[INTEG_MAX_LIN + 1];            // F, H, ..., H, F (internal, padded)
   const float* w[INTEG_MAX_LIN];          // per-member slices [member][chunk j][col][lane 0..63][4], K padded to 256
   const float* b[INTEG_MAX_LIN];          // full bias vectors
   int w_lds_off[INTEG_MAX_LIN];           // float offset of the LDS-resident copy, or -1 = stream from L2

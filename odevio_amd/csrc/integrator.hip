@@ -362,6 +362,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
 
   const bool seq_mode = (a.mode == MODE_ODE_RNN || a.mode == MODE_RNN_ONLY);
   const int F = a.F, Fp = pad256(F);
+  const int Fio = a.Fio;            // columns Fio .. F-1 are padding: zero weights in and out, their state stays exactly 0
   const int NCF = F / INTEG_MEMBERS;
   const int R = a.rows_per_group;
   const int BPG = a.BPG;
@@ -384,9 +385,9 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
     }
   }
   float y = 0.f;
-  if (owner && row_valid) {
-    if (seq_mode) y = a.hc ? a.hc[(size_t)grow * F + ocg] : 0.f;
-    else y = a.y0[(size_t)grow * F + ocg];
+  if (owner && row_valid && ocg < Fio) {
+    if (seq_mode) y = a.hc ? a.hc[(size_t)grow * Fio + ocg] : 0.f;
+    else y = a.y0[(size_t)grow * Fio + ocg];
   }
 
   // ---- placement census: the members tell each other their XCD through the SAFE protocol; only if all 32
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
 
   if (a.mode == MODE_FEVAL) {
     const float kk = feval(y);
-    if (owner && row_valid) a.y_out[(size_t)grow * F + ocg] = kk;
+    if (owner && row_valid && ocg < Fio) a.y_out[(size_t)grow * Fio + ocg] = kk;
     return;
   }
 
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
           float tot = 0.f;
           const int rr = orow < R ? orow : 0;
           for (int m = 0; m < INTEG_MEMBERS; ++m) tot += nrm[rr * INTEG_MEMBERS + m];
-          const float ratio = sqrtf(tot / (float)F);
+          const float ratio = sqrtf(tot / (float)Fio);   // (padded columns contribute exact zeros to the sum)
           accept = ratio < 1.0f;
           float factor = 0.9f * powf(ratio, inv_order);
           factor = fminf(fmaxf(factor, 0.2f), 10.0f);
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
         for (int i = tid; i < BPG * Fp; i += NT) {
           const int bi = i / Fp, col = i - bi * Fp;
           const int b = a.b_begin + g * BPG + bi;
-          xin[i] = (b < a.b_end && col < F) ? a.fused[((size_t)b * a.P + it) * F + col] : 0.f;
+          xin[i] = (b < a.b_end && col < Fio) ? a.fused[((size_t)b * a.P + it) * Fio + col] : 0.f;
         }
         __syncthreads();
       } else {
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
           hv = (1.f - zg) * ng + zg * hp;
         }
         mv[(l * BPG + orow) * 32 + ocl] = hv;
-        if (!more && b < a.b_end) a.out_seq[((size_t)b * a.P + it) * F + ug] = hv;
+        if (!more && b < a.b_end && ug < Fio) a.out_seq[((size_t)b * a.P + it) * Fio + ug] = hv;
         if (more) put(buf_of(c, c.epoch + 1) + orow * F + ug, hv, c.epoch + 1, c.local);
       }
       if (more) ++c.epoch;
@@ -710,8 +711,10 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
 #endif
   // ---- outputs
   if (owner && row_valid && !c.failed) {
-    if (seq_mode) a.hT[(size_t)grow * F + ocg] = y;
-    else a.y_out[(size_t)grow * F + ocg] = y;
+    if (ocg < Fio) {
+      if (seq_mode) a.hT[(size_t)grow * Fio + ocg] = y;
+      else a.y_out[(size_t)grow * Fio + ocg] = y;
+    }
     if (a.stats && cu == 0 && ocl == 0) {
       a.stats[2 * grow] = n_steps;
       a.stats[2 * grow + 1] = n_acc;
@@ -731,12 +734,14 @@ static int launch_rt(const IntegArgs& a, size_t lds_bytes, hipStream_t st) {
   static size_t checked_lds[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (first_use_on_device(attr_mask)) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_kernel<RT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  {
+    const hipError_t e = once_per_device(attr_mask, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    });
     if (e != hipSuccess) return (int)e;
   }
   const int grid = INTEG_GROUPS * INTEG_MEMBERS;
+  std::lock_guard<std::mutex> guard(launch_once_mutex());   // checked_lds is per process: plans of two host threads may launch at once
   if (checked_lds[dev & 63] != lds_bytes) {
     int per_cu = 0, n_cu = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(integrator_kernel<RT>),

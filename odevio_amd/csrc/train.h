@@ -74,6 +74,7 @@ int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, 
                   hipStream_t st);
 void skinny_linear(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, hipStream_t st);
 void leaky_inplace(float* x, size_t n, float slope, hipStream_t st);
+void mul_inplace(float* x, const float* y, size_t n, hipStream_t st);   // x *= y
 int train_fuse_hard_bwd(const float* W, const float* W_t, const float* bias, float* cat, float* logits, float* g_logits, float* g_cat,
                         const float* fv, int nv, const float* fi, int ni, int P, unsigned long long seed, unsigned long long call,
                         const float* g_fused, float* g_fv, float* g_fi, float* g_W, float* g_b, hipStream_t st);

@@ -33,7 +33,7 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // Skinny GEMMs on the fp32 MFMA (v_mfma_f32_16x16x4_f32: an exact fmaf chain).  One 4-wave workgroup per 16 x 16 output
 // tile; the waves take the 16-wide k-steps round robin and combine through LDS in wave order (deterministic).
-//   NT: out[m][n] (+)= sum_k A[m * lda + k] * W[n * ldw + k] (+ bias[n])          K % 16 == 0
+//   NT: out[m][n] (+)= sum_k A[m * lda + k] * W[n * ldw + k] (+ bias[n])          K % 4 == 0, lda % 4 == 0, ldw % 4 == 0
 //   TN: out[n][k] (+)= sum_m D[m * ldd + n] * A[m * lda + k]                      (weight gradients: contraction over rows)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int k = 16 * wave; k < K; k += 64) {
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k);
-    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + k);
+    // K % 4 == 0: a lane's four consecutive k are inside K or all outside (the tail of a K that is not a multiple of 16 adds zeros)
+    const bool in = k + 4 * q < K;
+    const f32x4 wv = in ? *reinterpret_cast<const f32x4*>(wrow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 av = in ? *reinterpret_cast<const f32x4*>(arow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc, 0, 0, 0);
   }
@@ -849,6 +851,8 @@ void skinny_linear(const float* A, int lda, const float* W, int ldw, const float
   gemm_nt(st, A, lda, W, ldw, bias, out, ldo, M, N, K);
 }
 void leaky_inplace(float* x, size_t n, float slope, hipStream_t st) { hipLaunchKernelGGL(leaky_kernel, EW_GRID(n), 0, st, x, n, slope); }
+__global__ void mul_kernel(float* x, const float* y, size_t n) { EW_LOOP(i, n) x[i] *= y[i]; }
+void mul_inplace(float* x, const float* y, size_t n, hipStream_t st) { hipLaunchKernelGGL(mul_kernel, EW_GRID(n), 0, st, x, y, n); }
 
 // FusionModule "hard" backward: logits = cat W^T + b recomputed, the element-wise part in pose.hip (same Philox block as the forward),
 // then g_W = g_logits^T cat, g_b = column sums, g_cat += g_logits W.

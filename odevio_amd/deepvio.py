@@ -164,13 +164,12 @@ class DeepVIO(nn.Module):
         self.Image_net = _ImageNet(opt)
         self.Inertial_net = _InertialNet(opt)
         if opt.model_type == "cde":
-            if opt.fuse_method == "hard":
-                raise ValueError("fuse_method 'hard' is not supported on the Neural-CDE path")
             self.Pose_net = _PoseCDENet(opt)
         else:
             self.Pose_net = _PoseNet(opt, with_ode=(opt.model_type == "ode-rnn"))
         self._plan = None
         self._plan_sig = None
+        self._rng = None
         self._warned_train = False
         self._lib = _lib.load()  # raises if the HIP library is missing: no silent fallback
         # the reference constructor leaves a random model behind (DeepVIO.py:43); ours is seeded
@@ -220,6 +219,9 @@ class DeepVIO(nn.Module):
         sig = self._signature()
         if self._plan is not None and sig == self._plan_sig:
             return
+        # the random stream (hard fusion's Gumbel noise, train-mode dropout) belongs to the MODEL, not to one plan: a rebuild after
+        # load_state_dict / .cuda() / a torch optimizer step must go on drawing fresh noise, not replay the stream from draw 0
+        rng = self._rng_of_plan()
         self._destroy_plan()
         sd = {k: v for k, v in self.state_dict().items() if v.is_floating_point()}
         keep = []  # keep contiguous fp32 views alive during the call
@@ -236,9 +238,23 @@ class DeepVIO(nn.Module):
             torch.cuda.current_stream().synchronize()
             _lib.check(self._lib.odevio_plan_create(ctypes.byref(cfg), arr, len(sd), self._stream(), ctypes.byref(plan)))
         self._plan, self._plan_sig = plan, sig
+        if rng is not None:
+            _lib.check(self._lib.odevio_set_rng_state(self._plan, rng[0], rng[1]))
+            self._rng = rng
+
+    def _rng_of_plan(self):
+        if getattr(self, "_plan", None) is None:
+            return getattr(self, "_rng", None)
+        seed, calls = ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self._lib.odevio_rng_state(self._plan, ctypes.byref(seed), ctypes.byref(calls)))
+        return int(seed.value), int(calls.value)
 
     def _destroy_plan(self):
         if getattr(self, "_plan", None) is not None:
+            try:
+                self._rng = self._rng_of_plan()   # survives an explicit destroy too
+            except Exception:
+                pass
             self._lib.odevio_plan_destroy(self._plan)
             self._plan = None
 

@@ -365,6 +365,8 @@ def test_pose_rnn_golden(dev, golden_dir, rnn_type, L, method):
     dict(ode_solver="dopri5", ode_rnn_type="gru", fuse_method="soft"),
     dict(ode_solver="tsit5", rnn_num_layers=3, ode_activation_fn="softplus", ode_fn_num_layers=2, ode_hidden_dim=1024,
          fuse_method="soft"),  # the reference's own training recipe (scripts/run_training.sh:6-28) with tsit5
+    dict(ode_solver="dopri5", rnn_num_layers=3, ode_activation_fn="softplus", ode_fn_num_layers=2, ode_hidden_dim=1024,
+         fuse_method="soft"),  # ... and with the recipe's real solver flag (dopri5, run_training.sh:17)
     dict(ode_solver="heun", rnn_num_layers=1),
 ])
 @pytest.mark.parametrize("B,drop", [(16, 0.0), (3, 0.5)])
