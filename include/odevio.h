@@ -179,6 +179,29 @@ int odevio_ode_rnn_bwd(odevio_plan* plan, const float* fused, const float* ts, c
  * n_rows = B*P rows; grad_poses [n_rows,6] = d loss3[0] / d poses, or NULL. */
 int odevio_pose_loss(const float* poses, const float* gts, int32_t n_rows, float* loss3, float* grad_poses, void* stream);
 
+/* ---- model.train() semantics of the encoders (the reference trains under model.train(), scripts/train_model.py:219: every
+ * BatchNorm of both encoders - the frozen Image_net's too - normalises with BATCH statistics and updates its running statistics,
+ * every Dropout is on; src/models/Encoder.py:8-22,43-57,82-90).
+ * ImageEncoder.forward in train mode: per block conv -> batch statistics over (N,H,W) -> gamma (z - mean) / sqrt(var + eps) + beta ->
+ * LeakyReLU(0.1) -> Dropout(0.2; conv6: 0.5), then the visual head.  `stats`: device tensors named like the module's buffers
+ * ("Image_net.conv3_1.1.running_mean" / ".running_var", fp32 [Cout]) that are updated IN PLACE as torch does (momentum 0.1, unbiased
+ * variance); buffers not listed are left alone (num_batches_tracked is the caller's counter).  Each block's dropout mask is one
+ * draw of the plan's random stream (9 draws, conv1 first; odevio_rng_state BEFORE the call gives the first).  fp32 frames only. */
+int odevio_image_encoder_fwd_train(odevio_plan* plan, const float* img, int32_t B, int32_t S, float* fv, int32_t ld_fv,
+                                   const odevio_tensor* stats, int32_t n_stats, void* stream);
+/* InertialEncoder.forward in train mode: BatchNorm1d over the (pair, time) rows of the batch, Dropout(p_drop = opt.imu_dropout)
+ * after every block; three draws of the random stream (consumed whatever p_drop is); `stats` as above
+ * ("Inertial_net.encoder_conv.1.running_mean", ...). */
+int odevio_imu_encoder_fwd_train(odevio_plan* plan, const float* imu, int32_t B, int32_t T, float p_drop, const odevio_tensor* stats,
+                                 int32_t n_stats, float* fi, int32_t ld_fi, void* stream);
+/* Its backward: gradients of every Inertial_net parameter through the batch-statistics BatchNorm (torch's batch_norm backward with
+ * training=True) and the dropout masks of draws call0 .. call0+2 of `seed` (what odevio_rng_state returned before the forward). */
+int odevio_imu_encoder_bwd_train(odevio_plan* plan, const float* imu, int32_t B, int32_t T, float p_drop, uint64_t seed, uint64_t call0,
+                                 const float* grad_fi, const odevio_tensor* grads, int32_t n_grads, void* stream);
+/* Test hook: the factor nn.Dropout(p_drop) applies to each of n elements under draw `call` of `seed` (0 or 1 / (1 - p_drop)) -> out [n]
+ * (device).  Element order: image encoder NHWC (pixel * C + channel), inertial encoder [pair][channel][time]. */
+int odevio_debug_dropout(uint64_t seed, uint64_t call, float p_drop, int64_t n, float* out, void* stream);
+
 /* Seed of the plan's random stream (Philox 4x32-10; fuse_method "hard" draws its Gumbel noise from it, one counter block per
  * call).  The same seed gives the same sequence of masks; plans start at seed 0. */
 int odevio_set_seed(odevio_plan* plan, uint64_t seed);
@@ -225,6 +248,11 @@ int odevio_grad_clip(odevio_plan* plan, const odevio_tensor* grads, int32_t n_gr
  * param, exp_avg, exp_avg_sq are updated in place; `step` counts from 1; norm_coef = the pair of odevio_grad_clip or NULL. */
 int odevio_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int32_t step, const float* norm_coef, void* stream);
+/* One torch.optim.SGD update of one tensor - the reference's other optimizer (utils/utils.py:120-121: SGD(param_groups, lr=1e-4,
+ * momentum=0.9), each group's own lr = lr_warmup): g = clip * grad + weight_decay * p; buf = g at step 1, else momentum * buf + g;
+ * p -= lr * buf.  norm_coef: the device pair written by odevio_grad_clip, or NULL. */
+int odevio_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t numel, float lr, float momentum, float weight_decay,
+                    int32_t step, const float* norm_coef, void* stream);
 
 /* After an optimizer step: re-reads the parameters of Pose_net (fusion, regressor, ODEFunc, RNN; every key of the
  * reference's Pose_net state_dict, device pointers) into the plan's kernel layouts, in place.  The encoders are not

@@ -27,6 +27,8 @@ SYMBOLS = [
     "odevio_ode_rnn_bwd", "odevio_pose_loss", "odevio_resize_u8", "odevio_resize_table",
     "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update", "odevio_imu_encoder_bwd", "odevio_set_seed",
     "odevio_rng_state", "odevio_debug_gumbel", "odevio_fuse_hard_bwd", "odevio_set_rng_state",
+    "odevio_image_encoder_fwd_train", "odevio_imu_encoder_fwd_train", "odevio_imu_encoder_bwd_train", "odevio_debug_dropout",
+    "odevio_sgd_step",
 ]
 
 
@@ -113,12 +115,17 @@ def load():
     lib.odevio_fuse_bwd.argtypes = [vp, fp, fp, i32, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_grad_clip.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, f32, fp, vp]
     lib.odevio_adam_step.argtypes = [fp, fp, fp, fp, ctypes.c_int64, f32, f32, f32, f32, f32, i32, fp, vp]
+    lib.odevio_sgd_step.argtypes = [fp, fp, fp, ctypes.c_int64, f32, f32, f32, i32, fp, vp]
     lib.odevio_plan_update.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_imu_encoder_bwd.argtypes = [vp, fp, i32, i32, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_set_seed.argtypes = [vp, ctypes.c_uint64]
     u64 = ctypes.c_uint64
     lib.odevio_rng_state.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     lib.odevio_set_rng_state.argtypes = [vp, u64, u64]
+    lib.odevio_image_encoder_fwd_train.argtypes = [vp, fp, i32, i32, fp, i32, ctypes.POINTER(OdevioTensor), i32, vp]
+    lib.odevio_imu_encoder_fwd_train.argtypes = [vp, fp, i32, i32, f32, ctypes.POINTER(OdevioTensor), i32, fp, i32, vp]
+    lib.odevio_imu_encoder_bwd_train.argtypes = [vp, fp, i32, i32, f32, u64, u64, fp, ctypes.POINTER(OdevioTensor), i32, vp]
+    lib.odevio_debug_dropout.argtypes = [u64, u64, f32, ctypes.c_int64, fp, vp]
     lib.odevio_debug_gumbel.argtypes = [u64, u64, ctypes.c_int64, fp, vp]
     lib.odevio_fuse_hard_bwd.argtypes = [vp, fp, fp, i32, u64, u64, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_resize_table.argtypes = [i32, i32, vp, vp, vp, i32]

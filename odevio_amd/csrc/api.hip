@@ -17,6 +17,7 @@
 #include "common.h"
 #include "integrator.h"
 #include "train.h"
+#include "bn_train.h"
 
 // roctx ranges at the two sites the reference marks with NVTX (src/models/PoseODERNN.py:103-104 "ODE", :118-119 "RNN"),
 // plus the encoders: visible in rocprofv3 --marker-trace.  libroctx64 is looked up at run time (no link dependency);
@@ -92,6 +93,16 @@ struct odevio_plan {
   float* conv_scale_c[9] = {};
   float* conv_shift_c[9] = {};
   int act_exp[10] = {};
+  // train mode (model.train(): BatchNorm with batch statistics + Dropout, bn_train.hip): the BatchNorm affine parameters, an
+  // identity epilogue for the convolution kernels (1 / prescale, zero shift, slope 1), scratch for the statistics
+  float* conv_gamma[9] = {};
+  float* conv_beta[9] = {};
+  float* conv_scale_raw[9] = {};
+  float* head_scale_raw = nullptr;
+  float* zero_vec = nullptr;     // 1024 zeros
+  float *bn_scale = nullptr, *bn_shift = nullptr;   // [1024] each: the affine pair of the block being normalised
+  float *imu_gamma[3] = {}, *imu_beta[3] = {};
+  DevBuf bn_partial;
   int conv_math = 1;       // 1: fp16x2 operand split on the fp16 MFMA (default); 0: fp32-input MFMA (ODEVIO_CONV_MATH=f32)
   DevBuf pack_tmp, ingest, partial_side;
   // the inertial encoder runs beside the image encoder on its own stream (odevio_forward)
@@ -334,7 +345,7 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side, &p->train_ws, &p->train_log, &p->train_aux})
+                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side, &p->train_ws, &p->train_log, &p->train_aux, &p->bn_partial})
     if (b->p) (void)hipFree(b->p);
   delete p;
 }
@@ -622,6 +633,12 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       std::vector<float> sch(sc);
       for (float& v : sch) v /= prescale;   // exact: prescale is a power of two
       TRY(upload(p, &p->conv_scale_h[i], sch, st));
+      std::vector<float> raw((size_t)cs.cout, 1.0f / prescale), gm, bt;   // train mode: z = conv(x) itself
+      TRY(upload(p, &p->conv_scale_raw[i], raw, st));
+      TRY(wt.get(pre + ".1.weight", cs.cout, gm));
+      TRY(wt.get(pre + ".1.bias", cs.cout, bt));
+      TRY(upload(p, &p->conv_gamma[i], gm, st));
+      TRY(upload(p, &p->conv_beta[i], bt, st));
     }
     TRY(upload(p, &p->conv_scale[i], sc, st));
     TRY(upload(p, &p->conv_shift[i], sh, st));
@@ -677,6 +694,8 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       HIPCHK(hipStreamSynchronize(st));
       std::vector<float> hs((size_t)cfg->v_f_len, std::ldexp(1.0f, -p->act_exp[9]) / prescale);   // conv6's stored output carries 2^act_exp[9]
       TRY(upload(p, &p->head_scale_h, hs, st));
+      std::vector<float> hr((size_t)cfg->v_f_len, 1.0f / prescale);   // train mode: activations carry no exponent
+      TRY(upload(p, &p->head_scale_raw, hr, st));
     }
     TRY(wt.get("Image_net.visual_head.bias", cfg->v_f_len, bias));
     TRY(upload(p, &p->head_b, bias, st));
@@ -707,6 +726,11 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
         TRY(wt.get(bn + ".running_var", cout[i], var));
         TRY(upload(p, &p->imu_mean[i], mu, st));
         TRY(upload(p, &p->imu_var[i], var, st));
+        std::vector<float> gm, bt;
+        TRY(wt.get(bn + ".weight", cout[i], gm));
+        TRY(wt.get(bn + ".bias", cout[i], bt));
+        TRY(upload(p, &p->imu_gamma[i], gm, st));
+        TRY(upload(p, &p->imu_beta[i], bt, st));
       }
     }
     TRY(wt.get("Inertial_net.proj.weight", (int64_t)cfg->i_f_len * 2816, w));
@@ -754,6 +778,12 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
         p->cde.w_last16 = d16;
       }
     }
+  }
+  {
+    std::vector<float> z(1024, 0.f);
+    TRY(upload(p, &p->zero_vec, z, st));
+    TRY(upload(p, &p->bn_scale, z, st));
+    TRY(upload(p, &p->bn_shift, z, st));
   }
   // ---- exchange buffers + status
   p->xstride = 8 * INTEG_KMAX;
@@ -943,8 +973,11 @@ static ConvPlanF plan_f16x2(int layer, int M, int N, int nk, int n_cu, bool off3
 
 // One encoder block.  Activations between blocks live in the P2 split layout when the fp16x2 kernel is in use
 // (in_split / out_split); fp32 NHWC otherwise.
+// mode 0: the block alone (activations in true units); 1: the production chain (per-layer activation exponents); 2: train mode -
+// an identity epilogue, z = conv(x): BatchNorm with batch statistics, LeakyReLU and Dropout follow as their own passes (bn_train.hip)
 static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void* out, bool in_split, bool out_split,
-                      hipStream_t st, bool in_u8 = false, bool chain = false) {
+                      hipStream_t st, bool in_u8 = false, int mode = 0) {
+  const bool chain = mode == 1;
   const int P = B * (S - 1);
   const ConvSpec& cs = kConvs[i];
   if (i == 0) {
@@ -968,6 +1001,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
       a.wt16 = p->conv_ws[0];
       a.scale = chain ? p->conv_scale_c[0] : p->conv_scale_h[0];
       if (chain) a.shift = p->conv_shift_c[0];
+      if (mode == 2) { a.scale = p->conv_scale_raw[0]; a.shift = p->zero_vec; a.slope = 1.0f; }
       a.terms = p->conv_math == 2 ? 1 : 3;
       HIPCHK(launch_conv1_f16x2(a, p->n_cu, st));
     } else {
@@ -984,6 +1018,7 @@ static int conv_block(odevio_plan* p, int i, const void* in, int B, int S, void*
     a.N = P; a.Hi = p->conv_h[i]; a.Wi = p->conv_w_sp[i]; a.Cin = cs.cin; a.Ho = p->conv_h[i + 1]; a.Wo = p->conv_w_sp[i + 1];
     a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = (cs.k - 1) / 2;
     a.M = P * a.Ho * a.Wo; a.slope = 0.1f; a.out_split = out_split; a.ld_out = cs.cout; a.terms = p->conv_math == 2 ? 1 : 3;
+    if (mode == 2) { a.scale = p->conv_scale_raw[i]; a.shift = p->zero_vec; a.slope = 1.0f; }
     a.in_bytes = extent_of(p, in, (size_t)P * a.Hi * a.Wi * a.Cin * sizeof(float));
     a.w_bytes = p->conv_ws_bytes[i];
     set_off32(p, a, in);
@@ -1062,6 +1097,8 @@ static int ensure_act(odevio_plan* p, int P) {
   return ensure(p->actB, nB);
 }
 
+static int visual_head(odevio_plan* p, const float* cur, int P, float* fv, int ld_fv, const float* head_scale, hipStream_t st);
+
 static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* fv, int ld_fv, hipStream_t st,
                          bool img_u8 = false) {
   RoctxRange range("odevio: ImageEncoder");
@@ -1070,20 +1107,28 @@ static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* f
   if ((rc = ensure_act(p, P))) return rc;
   const bool split = p->conv_math != 0;  // conv1 .. conv5_1 hand their output over in the P2 split layout
   stage_mark(p, 0, st);
-  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, false, split, st, img_u8, split))) return rc;
+  if ((rc = conv_block(p, 0, img, B, S, p->actA.p, false, split, st, img_u8, split ? 1 : 0))) return rc;
   stage_mark(p, 1, st);
   float* cur = p->actA.p;
   for (int i = 1; i < 9; ++i) {
     float* nxt = (cur == p->actA.p) ? p->actB.p : p->actA.p;
-    if ((rc = conv_block(p, i, cur, B, S, nxt, split, split, st, false, split))) return rc;
+    if ((rc = conv_block(p, i, cur, B, S, nxt, split, split, st, false, split ? 1 : 0))) return rc;
     cur = nxt;
   }
   stage_mark(p, 2, st);
+  rc = visual_head(p, cur, P, fv, ld_fv, p->head_scale_h, st);
+  stage_mark(p, 3, st);
+  return rc;
+}
+
+static int visual_head(odevio_plan* p, const float* cur, int P, float* fv, int ld_fv, const float* head_scale, hipStream_t st) {
+  const bool split = p->conv_math != 0;
+  int rc;
   if (split) {
     // visual head = a 1x1 convolution over conv6's P2 output seen as P 'pixels' of head_k channels: the 67 MB weight
     // stream split 64 ways over K so that every CU takes part
     ConvSplitArgs a{};
-    a.in = cur; a.w = p->head_ws; a.zeros = p->zero_page; a.scale = p->head_scale_h; a.shift = p->head_b; a.out = fv;
+    a.in = cur; a.w = p->head_ws; a.zeros = p->zero_page; a.scale = head_scale; a.shift = p->head_b; a.out = fv;
     a.status = p->status;
     a.N = P; a.Hi = a.Wi = a.Ho = a.Wo = 1; a.Cin = p->head_k; a.Cout = p->cfg.v_f_len; a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
     a.M = P; a.slope = 1.0f; a.out_split = 0; a.ld_out = ld_fv; a.terms = p->conv_math == 2 ? 1 : 3;
@@ -1105,8 +1150,41 @@ static int image_encoder(odevio_plan* p, const void* img, int B, int S, float* f
   } else {
     rc = run_gemm(p, cur, P, p->head_k, p->head_w, p->cfg.v_f_len, nullptr, p->head_b, nullptr, 0, fv, ld_fv, EPI_NONE, 0.f, st);
   }
-  stage_mark(p, 3, st);
   return rc;
+}
+
+// Named device tensors a caller hands in for in-place update (BatchNorm running statistics): pointer by name, or null
+static float* named_ptr(const odevio_tensor* t, int n, const std::string& name, int64_t numel) {
+  for (int i = 0; i < n; ++i)
+    if (t[i].name && t[i].data && name == t[i].name && t[i].numel == numel) return (float*)t[i].data;
+  return nullptr;
+}
+
+// ImageEncoder.forward under model.train() (Encoder.py:97-122 with every block's BatchNorm2d in batch-statistics mode and its
+// Dropout(0.2) - conv6: Dropout(0.5) - on, :82-90): per block conv (identity epilogue) -> batch statistics -> normalise +
+// LeakyReLU + dropout in place.  Each block's mask is one draw of the plan's random stream (9 draws per call, conv1 first).
+static int image_encoder_train(odevio_plan* p, const float* img, int B, int S, float* fv, int ld_fv, const odevio_tensor* stats, int n_stats,
+                               hipStream_t st) {
+  RoctxRange range("odevio: ImageEncoder (train mode)");
+  if (p->conv_math == 0) return fail(ODEVIO_ERR_UNSUPPORTED, "train-mode encoders need the fp16x2 encoder (unset ODEVIO_CONV_MATH=f32 / --dtype fp32_mfma)");
+  const int P = B * (S - 1);
+  int rc;
+  if ((rc = ensure_act(p, P)) || (rc = ensure(p->bn_partial, (size_t)4 * BN_MAX_BLOCKS * 1024))) return rc;   // doubles in a float buffer
+  float* cur = nullptr;
+  for (int i = 0; i < 9; ++i) {
+    const ConvSpec& cs = kConvs[i];
+    float* nxt = (i == 0 || cur == p->actB.p) ? p->actA.p : p->actB.p;
+    if ((rc = conv_block(p, i, i == 0 ? (const void*)img : (const void*)cur, B, S, nxt, i > 0, true, st, false, 2))) return rc;
+    const size_t M = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1];
+    const std::string bn = std::string("Image_net.") + cs.name + ".1";
+    HIPCHK(bn_stats_p2(nxt, M, cs.cout, reinterpret_cast<double*>(p->bn_partial.p), p->conv_gamma[i], p->conv_beta[i], 1e-5f, 0.1f,
+                       named_ptr(stats, n_stats, bn + ".running_mean", cs.cout), named_ptr(stats, n_stats, bn + ".running_var", cs.cout),
+                       p->bn_scale, p->bn_shift, st));
+    const DropoutSpec d = make_dropout(p->seed, p->rng_calls++, i == 8 ? 0.5f : 0.2f);
+    HIPCHK(bn_apply_p2(nxt, M, cs.cout, p->bn_scale, p->bn_shift, 0.1f, d, p->status, st));
+    cur = nxt;
+  }
+  return visual_head(p, cur, P, fv, ld_fv, p->head_scale_raw, st);
 }
 
 static int imu_encoder(odevio_plan* p, const float* imu, int B, int T, float* fi, int ld_fi, hipStream_t st,
@@ -1891,26 +1969,11 @@ extern "C" int odevio_fuse_bwd(odevio_plan* p, const float* fv, const float* fi,
   return 0;
 }
 
-extern "C" int odevio_imu_encoder_bwd(odevio_plan* p, const float* imu, int32_t B, int32_t T, const float* grad_fi, const odevio_tensor* grads,
-                                      int32_t n_grads, void* stream) {
-  ARGCHK(p && imu && grad_fi && B > 0 && T >= 11 && (T - 1) % 10 == 0 && n_grads >= 0 && (grads || n_grads == 0), "odevio_imu_encoder_bwd: bad argument");
-  hipStream_t st = (hipStream_t)stream;
-  POLL(p, st);
-  ImuTrain m{};
-  ImuGrads g{};
+static void fill_imu_train(odevio_plan* p, ImuTrain& m);
+static int parse_imu_grads(odevio_plan* p, const odevio_tensor* grads, int n_grads, ImuGrads& g, const char* who) {
   const int cin[3] = {6, 64, 128}, cout[3] = {64, 128, 256}, idx[3] = {0, 4, 8};
-  for (int i = 0; i < 3; ++i) {
-    m.w[i] = p->imu_wref[i]; m.wt[i] = p->imu_w[i]; m.s[i] = p->imu_s[i]; m.h[i] = p->imu_h[i];
-    m.var[i] = p->imu_var[i]; m.mean[i] = p->imu_mean[i]; m.bias[i] = p->imu_bias[i];
-    m.ldk[i] = (3 * cin[i] + 15) / 16 * 16;
-  }
-  m.eps = 1e-5f;
-  m.proj_w = p->proj_w;
-  m.i_f_len = p->cfg.i_f_len;
-  if (m.i_f_len % 16 || m.i_f_len > 256)   // (the workspace holds the transposed projection as [2816][<= 256])
-    return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_imu_encoder_bwd: i_f_len must be a multiple of 16, at most 256");
   for (int j = 0; j < n_grads; ++j) {
-    if (!grads[j].name || !grads[j].data) return fail(ODEVIO_ERR_BAD_ARG, "odevio_imu_encoder_bwd: gradient %d has no name / pointer", j);
+    if (!grads[j].name || !grads[j].data) return fail(ODEVIO_ERR_BAD_ARG, "%s: gradient %d has no name / pointer", who, j);
     const std::string nm = grads[j].name;
     float* dst = (float*)grads[j].data;
     int64_t want = -1;
@@ -1922,18 +1985,113 @@ extern "C" int odevio_imu_encoder_bwd(odevio_plan* p, const float* imu, int32_t 
       else if (nm == bn + ".bias") { g.beta[i] = dst; want = cout[i]; }
     }
     if (want < 0) {
-      if (nm == "Inertial_net.proj.weight") { g.proj_w = dst; want = (int64_t)m.i_f_len * 2816; }
-      else if (nm == "Inertial_net.proj.bias") { g.proj_b = dst; want = m.i_f_len; }
+      if (nm == "Inertial_net.proj.weight") { g.proj_w = dst; want = (int64_t)p->cfg.i_f_len * 2816; }
+      else if (nm == "Inertial_net.proj.bias") { g.proj_b = dst; want = p->cfg.i_f_len; }
     }
-    if (want < 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_imu_encoder_bwd: '%s' is not a parameter of Inertial_net", nm.c_str());
-    if (want != grads[j].numel) return fail(ODEVIO_ERR_BAD_ARG, "odevio_imu_encoder_bwd: gradient '%s' has the wrong size", nm.c_str());
+    if (want < 0) return fail(ODEVIO_ERR_BAD_ARG, "%s: '%s' is not a parameter of Inertial_net", who, nm.c_str());
+    if (want != grads[j].numel) return fail(ODEVIO_ERR_BAD_ARG, "%s: gradient '%s' has the wrong size", who, nm.c_str());
   }
+  return 0;
+}
+
+extern "C" int odevio_imu_encoder_bwd(odevio_plan* p, const float* imu, int32_t B, int32_t T, const float* grad_fi, const odevio_tensor* grads,
+                                      int32_t n_grads, void* stream) {
+  ARGCHK(p && imu && grad_fi && B > 0 && T >= 11 && (T - 1) % 10 == 0 && n_grads >= 0 && (grads || n_grads == 0), "odevio_imu_encoder_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  ImuTrain m{};
+  ImuGrads g{};
+  fill_imu_train(p, m);
+  if (m.i_f_len % 4 || m.i_f_len > 256)   // (the workspace holds the transposed projection as [2816][<= 256])
+    return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_imu_encoder_bwd: i_f_len must be a multiple of 4, at most 256");
+  int rc = parse_imu_grads(p, grads, n_grads, g, "odevio_imu_encoder_bwd");
+  if (rc) return rc;
   const int P = B * ((T - 1) / 10);
-  int rc;
   if ((rc = ensure(p->train_aux, train_imu_workspace_floats(P)))) return rc;
   rc = train_imu_bwd(m, p->train_aux.p, imu, B, T, grad_fi, nullptr, g, st);
   if (rc) return fail(rc, "odevio_imu_encoder_bwd: %s", hipGetErrorString(hipGetLastError()));
   return 0;
+}
+
+// ---- model.train() forward of the encoders, and the inertial encoder's backward through batch-statistics BatchNorm + Dropout
+static void fill_imu_train(odevio_plan* p, ImuTrain& m) {
+  const int cin[3] = {6, 64, 128};
+  for (int i = 0; i < 3; ++i) {
+    m.w[i] = p->imu_wref[i]; m.wt[i] = p->imu_w[i]; m.s[i] = p->imu_s[i]; m.h[i] = p->imu_h[i];
+    m.var[i] = p->imu_var[i]; m.mean[i] = p->imu_mean[i]; m.bias[i] = p->imu_bias[i];
+    m.ldk[i] = (3 * cin[i] + 15) / 16 * 16;
+  }
+  m.eps = 1e-5f;
+  m.proj_w = p->proj_w;
+  m.i_f_len = p->cfg.i_f_len;
+}
+static void fill_imu_train_mode(odevio_plan* p, ImuTrainMode& tm, float p_drop, unsigned long long seed, unsigned long long call0,
+                                const odevio_tensor* stats, int n_stats) {
+  const int cout[3] = {64, 128, 256}, idx[3] = {1, 5, 9};
+  for (int i = 0; i < 3; ++i) {
+    tm.gamma[i] = p->imu_gamma[i]; tm.beta[i] = p->imu_beta[i];
+    const std::string bn = "Inertial_net.encoder_conv." + std::to_string(idx[i]);
+    tm.run_mean[i] = named_ptr(stats, n_stats, bn + ".running_mean", cout[i]);
+    tm.run_var[i] = named_ptr(stats, n_stats, bn + ".running_var", cout[i]);
+    tm.drop[i] = make_dropout(seed, call0 + i, p_drop);
+  }
+  tm.momentum = 0.1f;   // nn.BatchNorm1d default (Encoder.py:45)
+}
+
+extern "C" int odevio_image_encoder_fwd_train(odevio_plan* p, const float* img, int32_t B, int32_t S, float* fv, int32_t ld_fv,
+                                              const odevio_tensor* stats, int32_t n_stats, void* stream) {
+  ARGCHK(p && img && fv && B > 0 && S > 1 && ld_fv >= p->cfg.v_f_len && n_stats >= 0 && (stats || n_stats == 0),
+         "odevio_image_encoder_fwd_train: bad argument");
+  POLL(p, stream);
+  const int rc = image_encoder_train(p, img, B, S, fv, ld_fv, stats, n_stats, (hipStream_t)stream);
+  post_status(p, (hipStream_t)stream);
+  return rc;
+}
+
+extern "C" int odevio_imu_encoder_fwd_train(odevio_plan* p, const float* imu, int32_t B, int32_t T, float p_drop, const odevio_tensor* stats,
+                                            int32_t n_stats, float* fi, int32_t ld_fi, void* stream) {
+  ARGCHK(p && imu && fi && B > 0 && T >= 11 && ld_fi >= p->cfg.i_f_len && p_drop >= 0.f && p_drop < 1.f && n_stats >= 0 && (stats || n_stats == 0),
+         "odevio_imu_encoder_fwd_train: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  ImuTrain m{};
+  ImuTrainMode tm{};
+  fill_imu_train(p, m);
+  fill_imu_train_mode(p, tm, p_drop, p->seed, p->rng_calls, stats, n_stats);
+  p->rng_calls += 3;   // one draw per block, whatever p_drop is (the stream position never depends on a flag)
+  const int P = B * ((T - 1) / 10);
+  int rc;
+  if ((rc = ensure(p->train_aux, train_imu_train_workspace_floats(P)))) return rc;
+  rc = train_imu_fwd_train(m, tm, p->train_aux.p, imu, B, T, p->proj_b, fi, ld_fi, st);
+  if (rc) return fail(rc, "odevio_imu_encoder_fwd_train: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+extern "C" int odevio_imu_encoder_bwd_train(odevio_plan* p, const float* imu, int32_t B, int32_t T, float p_drop, uint64_t seed, uint64_t call0,
+                                            const float* grad_fi, const odevio_tensor* grads, int32_t n_grads, void* stream) {
+  ARGCHK(p && imu && grad_fi && B > 0 && T >= 11 && (T - 1) % 10 == 0 && p_drop >= 0.f && p_drop < 1.f && n_grads >= 0 && (grads || n_grads == 0),
+         "odevio_imu_encoder_bwd_train: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  ImuTrain m{};
+  ImuTrainMode tm{};
+  ImuGrads g{};
+  fill_imu_train(p, m);
+  fill_imu_train_mode(p, tm, p_drop, seed, call0, nullptr, 0);
+  if (m.i_f_len % 4 || m.i_f_len > 256) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_imu_encoder_bwd_train: i_f_len must be a multiple of 4, at most 256");
+  int rc = parse_imu_grads(p, grads, n_grads, g, "odevio_imu_encoder_bwd_train");
+  if (rc) return rc;
+  const int P = B * ((T - 1) / 10);
+  if ((rc = ensure(p->train_aux, train_imu_train_workspace_floats(P)))) return rc;
+  rc = train_imu_bwd_train(m, tm, p->train_aux.p, imu, B, T, grad_fi, g, st);
+  if (rc) return fail(rc, "odevio_imu_encoder_bwd_train: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+extern "C" int odevio_debug_dropout(uint64_t seed, uint64_t call, float p_drop, int64_t n, float* out, void* stream) {
+  ARGCHK(out && n > 0 && p_drop >= 0.f && p_drop < 1.f, "odevio_debug_dropout: bad argument");
+  launch_dropout_dump(out, (size_t)n, make_dropout(seed, call, p_drop), (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? 0 : fail(ODEVIO_ERR_HIP, "odevio_debug_dropout: launch failed");
 }
 
 extern "C" int odevio_grad_clip(odevio_plan* p, const odevio_tensor* grads, int32_t n_grads, float max_norm, float* norm_coef,
@@ -1961,6 +2119,15 @@ extern "C" int odevio_adam_step(float* param, const float* grad, float* exp_avg,
          "odevio_adam_step: bad argument");
   if (train_adam_step(param, grad, exp_avg, exp_avg_sq, (size_t)numel, lr, beta1, beta2, eps, weight_decay, step, norm_coef, (hipStream_t)stream))
     return fail(ODEVIO_ERR_HIP, "odevio_adam_step: launch failed");
+  return 0;
+}
+
+extern "C" int odevio_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t numel, float lr, float momentum, float weight_decay,
+                               int32_t step, const float* norm_coef, void* stream) {
+  ARGCHK(param && grad && numel > 0 && step >= 1 && lr >= 0.f && momentum >= 0.f && weight_decay >= 0.f && (momentum_buf || momentum == 0.f),
+         "odevio_sgd_step: bad argument");
+  if (train_sgd_step(param, grad, momentum_buf, (size_t)numel, lr, momentum, weight_decay, step, norm_coef, (hipStream_t)stream))
+    return fail(ODEVIO_ERR_HIP, "odevio_sgd_step: launch failed");
   return 0;
 }
 

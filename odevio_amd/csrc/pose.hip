@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -144,19 +145,6 @@ hipError_t launch_path_accu(const void* poses, int is_f64, const int64_t* offset
 // generator; here the two uniforms of element j come from Philox 4x32-10 keyed by the plan's seed, counter = (element / 2,
 // call): reproducible per seed, never bit-equal to torch.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
-  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
-  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
 __device__ __forceinline__ float gumbel_from_bits(unsigned bits) {
   const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1), 24 bits
   return -logf(-logf(u));

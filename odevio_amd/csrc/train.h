@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include "philox.h"
+
 #define TRAIN_MAX_LIN 6
 #define TRAIN_MAX_L 4
 
@@ -50,6 +52,9 @@ int train_grad_clip(const float* const* grads, const size_t* numel, int n, float
 // one torch.optim.Adam update of one tensor; clip2 = the device pair written by train_grad_clip (or null)
 int train_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
                     const float* clip2, hipStream_t st);
+// one torch.optim.SGD update (momentum buffer `buf`; step 1 initialises it with the gradient like torch does)
+int train_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int step, const float* clip2,
+                   hipStream_t st);
 // parameter re-layout on the device (the index maps of odevio_plan_create's host code)
 void relayout_transpose(const float* src, float* dst, int N, int K, hipStream_t st);
 void relayout_shard(const float* W, float* out, int N, int K, int members, hipStream_t st);
@@ -69,6 +74,20 @@ struct ImuGrads {       // reference shapes; null = not wanted
   float *w[3], *b[3], *gamma[3], *beta[3], *proj_w, *proj_b;
 };
 size_t train_imu_workspace_floats(int P);
+// The same encoder under model.train(): BatchNorm1d with batch statistics (+ running-statistics update in the forward), Dropout.
+// gamma / beta: the BatchNorm affine parameters; run_mean / run_var: the module's buffers, updated in place by the forward (may be
+// null); drop[l]: the mask of block l (philox.h).  The backward recomputes the forward with the same masks.
+struct ImuTrainMode {
+  const float *gamma[3], *beta[3];
+  float *run_mean[3], *run_var[3];
+  float momentum;
+  DropoutSpec drop[3];
+};
+size_t train_imu_train_workspace_floats(int P);
+int train_imu_fwd_train(const ImuTrain& m, const ImuTrainMode& tm, float* ws, const float* imu, int B, int T, const float* proj_b, float* fi,
+                        int ld_fi, hipStream_t st);
+int train_imu_bwd_train(const ImuTrain& m, const ImuTrainMode& tm, float* ws, const float* imu, int B, int T, const float* g_fi, const ImuGrads& g,
+                        hipStream_t st);
 // imu [B][T][6], g_fi [B * (T-1)/10][i_f_len] contiguous; g_imu_rows (optional) [(pair, t)][6]: gradient w.r.t. the windowed samples
 int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, const float* g_fi, float* g_imu_rows, const ImuGrads& g,
                   hipStream_t st);

@@ -29,6 +29,7 @@
 #include "../../include/odevio.h"
 #include "common.h"
 #include "train.h"
+#include "bn_train.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Skinny GEMMs on the fp32 MFMA (v_mfma_f32_16x16x4_f32: an exact fmaf chain).  One 4-wave workgroup per 16 x 16 output
@@ -618,6 +619,30 @@ int train_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
 
+// torch.optim.SGD(momentum, dampening 0, no Nesterov, weight_decay wd), single tensor (torch/optim/sgd.py _single_tensor_sgd): the
+// reference's other optimizer (utils/utils.py:120-121: SGD(param_groups, lr=1e-4, momentum=0.9); the groups' own lr overrides it)
+//   g = clip * grad + wd * p;  buf = g (first step) | momentum buf + g;  p -= lr * buf
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n, float lr, float momentum,
+                           float wd, int first, const float* __restrict__ clip2) {
+  const float clip = clip2 ? clip2[1] : 1.0f;
+  EW_LOOP(i, n) {
+    const float pi = p[i];
+    float gi = g[i] * clip;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float bi = gi;
+    if (momentum != 0.f) {
+      bi = first ? gi : fmaf(momentum, buf[i], gi);
+      buf[i] = bi;
+    }
+    p[i] = pi - lr * bi;
+  }
+}
+int train_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int step, const float* clip2,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(sgd_kernel, EW_GRID(n), 0, st, p, g, buf, n, lr, momentum, wd, step <= 1 ? 1 : 0, clip2);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Parameter re-layout on the device (odevio_plan_update): the same index maps as the host code of odevio_plan_create
 // (api.hip: transposed(), shard_columns(), the RNN's virtual matrix), so that an optimizer step needs no host round trip.
@@ -840,6 +865,142 @@ int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, 
     if (l > 1 || g_imu_rows) {
       gemm_nt(st, D, Co, m.wt[l - 1], Co, nullptr, gcol, 3 * Ci, (int)rows, 3 * Ci, Co);         // g_xcol = D W
       hipLaunchKernelGGL(col2im3_kernel, EW_GRID(rows * Ci), 0, st, gcol, l > 1 ? gy : g_imu_rows, rows, Ci);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// InertialEncoder under model.train() (scripts/train_model.py:219; Encoder.py:43-57): BatchNorm1d with BATCH statistics over
+// every (pair, time step) row of the batch, running statistics updated, Dropout(opt.imu_dropout) after every block.  Same row
+// formulation as above; c = Conv1d(x) + bias this time (the bias cancels in the normalised value but not in running_mean).
+//   xhat = (c - mean) invstd;  y = leaky(gamma xhat + beta);  x_next = y * mask / (1 - p)
+// backward:  dz = g * mask / (1 - p) * leaky'(y);  g_beta = sum dz;  g_gamma = sum dz xhat;
+//            D = gamma invstd (dz - g_beta / N - xhat g_gamma / N)   (torch's batch_norm backward with training=True)
+// The dropout element index is the reference tensor's own order [pair][channel][time]: e = (pair * C + c) * 11 + t.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void bn_train_rows_fwd_kernel(const float* __restrict__ c, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, DropoutSpec drop, float* __restrict__ x,
+                                         size_t rows, int C) {
+  EW_LOOP(i, rows * C) {
+    const int ch = (int)(i % C);
+    const size_t r = i / C;
+    const float xh = (c[i] - mean[ch]) * invstd[ch];
+    float y = fmaf(gamma[ch], xh, beta[ch]);
+    y = y > 0.f ? y : 0.1f * y;
+    const unsigned long long e = ((unsigned long long)(r / IMU_T) * C + ch) * IMU_T + (unsigned long long)(r % IMU_T);
+    x[i] = y * dropout_factor(drop, e);
+  }
+}
+__global__ void bn_train_rows_bwd1_kernel(const float* __restrict__ g, const float* __restrict__ c, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          DropoutSpec drop, float* __restrict__ dz, float* __restrict__ dzx, size_t rows, int C) {
+  EW_LOOP(i, rows * C) {
+    const int ch = (int)(i % C);
+    const size_t r = i / C;
+    const float xh = (c[i] - mean[ch]) * invstd[ch];
+    const float y = fmaf(gamma[ch], xh, beta[ch]);
+    const unsigned long long e = ((unsigned long long)(r / IMU_T) * C + ch) * IMU_T + (unsigned long long)(r % IMU_T);
+    const float d = g[i] * dropout_factor(drop, e) * (y > 0.f ? 1.f : 0.1f);
+    dz[i] = d;
+    dzx[i] = d * xh;
+  }
+}
+__global__ void bn_train_rows_bwd2_kernel(const float* __restrict__ dz, const float* __restrict__ c, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ dH,
+                                          const float* __restrict__ dS, float* __restrict__ D, size_t rows, int C) {
+  const float invn = 1.0f / (float)rows;
+  EW_LOOP(i, rows * C) {
+    const int ch = (int)(i % C);
+    const float xh = (c[i] - mean[ch]) * invstd[ch];
+    D[i] = gamma[ch] * invstd[ch] * (dz[i] - dH[ch] * invn - xh * dS[ch] * invn);
+  }
+}
+__global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) { EW_LOOP(i, n) b[i] = a[i]; }
+
+size_t train_imu_train_workspace_floats(int P) { return train_imu_workspace_floats(P) + 2048; }
+
+// the recomputed train-mode forward shared by both entry points; stats[l] = {mean, invstd} of block l in ws
+static int imu_train_forward(const ImuTrain& m, const ImuTrainMode& tm, bool update_running, float* const (&x)[4], float* const (&c)[4],
+                             float* xcol, float* const (&mean)[3], float* const (&invstd)[3], const float* imu, int B, int T, hipStream_t st) {
+  const int pps = (T - 1) / 10, P = B * pps;
+  const size_t rows = (size_t)P * IMU_T;
+  const int C[4] = {6, 64, 128, 256};
+  hipLaunchKernelGGL(imu_window_kernel, EW_GRID(rows * 6), 0, st, imu, x[0], B, T, pps);
+  for (int l = 1; l < 4; ++l) {
+    hipLaunchKernelGGL(im2col3_kernel, EW_GRID(rows * m.ldk[l - 1]), 0, st, x[l - 1], xcol, rows, C[l - 1], m.ldk[l - 1]);
+    gemm_nt(st, xcol, m.ldk[l - 1], m.w[l - 1], m.ldk[l - 1], m.bias[l - 1], c[l], C[l], (int)rows, C[l], m.ldk[l - 1]);
+    if (bn_stats_rows(c[l], rows, C[l], m.eps, tm.momentum, update_running ? tm.run_mean[l - 1] : nullptr,
+                      update_running ? tm.run_var[l - 1] : nullptr, mean[l - 1], invstd[l - 1], st) != hipSuccess)
+      return ODEVIO_ERR_HIP;
+    hipLaunchKernelGGL(bn_train_rows_fwd_kernel, EW_GRID(rows * C[l]), 0, st, c[l], mean[l - 1], invstd[l - 1], tm.gamma[l - 1], tm.beta[l - 1],
+                       tm.drop[l - 1], x[l], rows, C[l]);
+  }
+  return 0;
+}
+
+#define IMU_TRAIN_CARVE()                                                   \
+  const int pps = (T - 1) / 10, P = B * pps;                                \
+  const size_t rows = (size_t)P * IMU_T;                                    \
+  const int C[4] = {6, 64, 128, 256};                                       \
+  float* x[4];                                                              \
+  float* c[4] = {nullptr, nullptr, nullptr, nullptr};                       \
+  float* w = ws;                                                            \
+  for (int l = 0; l < 4; ++l) { x[l] = w; w += rows * C[l]; }               \
+  for (int l = 1; l < 4; ++l) { c[l] = w; w += rows * C[l]; }               \
+  float* xcol = w; w += rows * 384;                                         \
+  float* dz = w; w += rows * 256;                                           \
+  float* dzc = w; w += rows * 256;                                          \
+  float* D = w; w += rows * 256;                                            \
+  float* gy = w; w += rows * 256;                                           \
+  float* gcol = w; w += rows * 384;                                         \
+  float* flat = w; w += rows * 256;                                         \
+  float* gflat = w; w += rows * 256;                                        \
+  float* dS = w; w += 256;                                                  \
+  float* dH = w; w += 256;                                                  \
+  w += 512;                                                                 \
+  float* projT = w; w += (size_t)2816 * 256;                                \
+  float* mean[3]; float* invstd[3];                                         \
+  for (int l = 0; l < 3; ++l) { mean[l] = w; w += 256; invstd[l] = w; w += 256; }
+
+int train_imu_fwd_train(const ImuTrain& m, const ImuTrainMode& tm, float* ws, const float* imu, int B, int T, const float* proj_b, float* fi,
+                        int ld_fi, hipStream_t st) {
+  IMU_TRAIN_CARVE();
+  (void)dz; (void)dzc; (void)D; (void)gy; (void)gcol; (void)gflat; (void)dS; (void)dH; (void)projT; (void)C;
+  const int rc = imu_train_forward(m, tm, true, x, c, xcol, mean, invstd, imu, B, T, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rows_to_ct_kernel, EW_GRID(rows * 256), 0, st, x[3], flat, (size_t)P, 256);
+  gemm_nt(st, flat, 2816, m.proj_w, 2816, proj_b, fi, ld_fi, P, m.i_f_len, 2816);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}
+
+int train_imu_bwd_train(const ImuTrain& m, const ImuTrainMode& tm, float* ws, const float* imu, int B, int T, const float* g_fi, const ImuGrads& g,
+                        hipStream_t st) {
+  IMU_TRAIN_CARVE();
+  const int NF = m.i_f_len;
+  int rc = imu_train_forward(m, tm, false, x, c, xcol, mean, invstd, imu, B, T, st);   // same masks, same statistics; running stats untouched
+  if (rc) return rc;
+  hipLaunchKernelGGL(rows_to_ct_kernel, EW_GRID(rows * 256), 0, st, x[3], flat, (size_t)P, 256);
+  if (g.proj_w) gemm_tn(st, g_fi, NF, flat, 2816, g.proj_w, 2816, P, NF, 2816);
+  if (g.proj_b) launch_colsum(st, g_fi, g.proj_b, P, NF);
+  relayout_transpose(m.proj_w, projT, NF, 2816, st);
+  gemm_nt(st, g_fi, NF, projT, NF, nullptr, gflat, 2816, P, 2816, NF);
+  hipLaunchKernelGGL(ct_to_rows_kernel, EW_GRID(rows * 256), 0, st, gflat, gy, (size_t)P, 256);
+  for (int l = 3; l >= 1; --l) {
+    const int Co = C[l], Ci = C[l - 1], ldk = m.ldk[l - 1];
+    hipLaunchKernelGGL(bn_train_rows_bwd1_kernel, EW_GRID(rows * Co), 0, st, gy, c[l], mean[l - 1], invstd[l - 1], tm.gamma[l - 1], tm.beta[l - 1],
+                       tm.drop[l - 1], dz, dzc, rows, Co);
+    launch_colsum(st, dz, dH, (int)rows, Co);
+    launch_colsum(st, dzc, dS, (int)rows, Co);
+    hipLaunchKernelGGL(bn_train_rows_bwd2_kernel, EW_GRID(rows * Co), 0, st, dz, c[l], mean[l - 1], invstd[l - 1], tm.gamma[l - 1], dH, dS, D, rows, Co);
+    if (g.gamma[l - 1]) hipLaunchKernelGGL(copy_kernel, EW_GRID(Co), 0, st, dS, g.gamma[l - 1], (size_t)Co);
+    if (g.beta[l - 1]) hipLaunchKernelGGL(copy_kernel, EW_GRID(Co), 0, st, dH, g.beta[l - 1], (size_t)Co);
+    if (g.b[l - 1]) launch_colsum(st, D, g.b[l - 1], (int)rows, Co);
+    hipLaunchKernelGGL(im2col3_kernel, EW_GRID(rows * ldk), 0, st, x[l - 1], xcol, rows, Ci, ldk);
+    if (g.w[l - 1]) gemm_tn(st, D, Co, xcol, ldk, g.w[l - 1], 3 * Ci, (int)rows, Co, 3 * Ci);
+    if (l > 1) {
+      gemm_nt(st, D, Co, m.wt[l - 1], Co, nullptr, gcol, 3 * Ci, (int)rows, 3 * Ci, Co);
+      hipLaunchKernelGGL(col2im3_kernel, EW_GRID(rows * Ci), 0, st, gcol, gy, rows, Ci);
     }
   }
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;

@@ -170,6 +170,7 @@ class DeepVIO(nn.Module):
         self._plan = None
         self._plan_sig = None
         self._rng = None
+        self._bn_dirty = False   # a train-mode forward moved the BatchNorm running statistics the plan's eval-mode constants were folded from
         self._warned_train = False
         self._lib = _lib.load()  # raises if the HIP library is missing: no silent fallback
         # the reference constructor leaves a random model behind (DeepVIO.py:43); ours is seeded
@@ -217,8 +218,9 @@ class DeepVIO(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("odevio_amd.DeepVIO runs on an MI355X only: move the model with .cuda() (no CPU path)")
         sig = self._signature()
-        if self._plan is not None and sig == self._plan_sig:
+        if self._plan is not None and sig == self._plan_sig and not (self._bn_dirty and not self.training):
             return
+        self._bn_dirty = False
         # the random stream (hard fusion's Gumbel noise, train-mode dropout) belongs to the MODEL, not to one plan: a rebuild after
         # load_state_dict / .cuda() / a torch optimizer step must go on drawing fresh noise, not replay the stream from draw 0
         rng = self._rng_of_plan()
@@ -278,13 +280,21 @@ class DeepVIO(nn.Module):
     def forward(self, img, imu, timestamps, hc=None):
         """img [B,S,3,H,W], imu [B,10(S-1)+1(+tail),6], timestamps [B,S], hc None | [L,B,F] -> (poses [B,S-1,6], h_T [L,B,F])."""
         self._ensure_plan()
-        if self.training and self.opt.model_type != "cde" and not self._warned_train:
-            # the reference's training caller runs in train() (scripts/train_model.py:69); this forward has no autograd
-            # graph and uses BatchNorm running statistics: say so once instead of silently computing eval semantics
-            import warnings
-            warnings.warn("odevio_amd.DeepVIO.forward computes inference (eval-mode BatchNorm, no autograd graph) even in "
-                          "train(); use odevio_amd.train.OdeRnnFunction for gradients through the integrator", stacklevel=2)
-            self._warned_train = True
+        if self.training:
+            # model.train() (scripts/train_model.py:69,219): both encoders normalise with BATCH statistics, move their running
+            # statistics and apply Dropout - computed here as the reference computes it; what this forward does NOT carry is an
+            # autograd graph (gradients: odevio_amd.train.pose_net / PoseNetTrainer): said once
+            if torch.is_grad_enabled() and not self._warned_train:
+                import warnings
+                warnings.warn("odevio_amd.DeepVIO.forward in train(): train-mode BatchNorm / Dropout semantics, but no autograd graph; "
+                              "use odevio_amd.train (pose_net, PoseNetTrainer) for gradients", stacklevel=2)
+                self._warned_train = True
+            if img.dtype == torch.uint8:
+                raise ValueError("train mode takes the loader's float frames [B,S,3,H,W] (uint8 frames: eval mode)")
+            fv, fi = self.image_encoder(img), self.imu_encoder(imu)
+            if self.opt.model_type == "cde":
+                return self.pose_cde(fv, fi, timestamps, hc)
+            return self.pose_net(fv, fi, timestamps, hc)
         if img.dtype == torch.uint8 and self.opt.model_type == "cde":
             raise ValueError("uint8 frames are supported for model_type ode-rnn / rnn")
         if self.opt.model_type == "cde":
@@ -321,11 +331,42 @@ class DeepVIO(nn.Module):
         return poses, h_T
 
     # ------------------------------------------------------------------ component entry points (tests, bench)
+    def _bn_buffers(self, net, prefix):
+        """(names, tensors) of the running statistics of `net`'s BatchNorm layers (updated in place by the train-mode kernels) and
+        the list of their num_batches_tracked counters."""
+        names, tensors, counters = [], [], []
+        for k, b in net.named_buffers():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                if not (b.is_cuda and b.dtype == torch.float32 and b.is_contiguous()):
+                    raise RuntimeError("BatchNorm buffers must be contiguous fp32 tensors on the GPU (model.cuda())")
+                names.append(prefix + k)
+                tensors.append(b)
+            elif k.endswith("num_batches_tracked"):
+                counters.append(b)
+        return names, tensors, counters
+
+    def _after_train_forward(self, counters):
+        for c in counters:
+            c += 1                              # what nn.BatchNorm does in train mode (the kernels moved mean / var in place)
+        self._plan_sig = self._signature()      # the plan's train-mode inputs are these very buffers: nothing to rebuild ...
+        self._bn_dirty = True                   # ... until an eval-mode forward needs the running statistics folded again
+
     def image_encoder(self, img):
+        """ImageEncoder.forward (Encoder.py:97-122).  In ``train()`` mode: BatchNorm with batch statistics, the modules' running
+        statistics updated in place, Dropout(0.2 / 0.5) with masks from the model's random stream (``set_seed`` / ``rng_state``)."""
         self._ensure_plan()
         img = self._dev(img, "img")
         B, S = img.shape[0], img.shape[1]
         fv = torch.empty(B, S - 1, self.opt.v_f_len, device=img.device, dtype=torch.float32)
+        if self.training:
+            names, tensors, counters = self._bn_buffers(self.Image_net, "Image_net.")
+            arr = (_lib.OdevioTensor * len(names))()
+            for i, (n, t) in enumerate(zip(names, tensors)):
+                arr[i].name, arr[i].data, arr[i].numel = n.encode(), t.data_ptr(), t.numel()
+            _lib.check(self._lib.odevio_image_encoder_fwd_train(self._plan, img.data_ptr(), B, S, fv.data_ptr(), self.opt.v_f_len, arr,
+                                                                len(names), self._stream()))
+            self._after_train_forward(counters)
+            return fv
         _lib.check(self._lib.odevio_image_encoder_fwd(self._plan, img.data_ptr(), B, S, fv.data_ptr(), self.opt.v_f_len,
                                                       self._stream()))
         return fv
@@ -342,13 +383,33 @@ class DeepVIO(nn.Module):
         return out
 
     def imu_encoder(self, imu):
+        """InertialEncoder.forward (Encoder.py:60-74); ``train()`` mode as in ``image_encoder`` with Dropout(opt.imu_dropout)."""
         self._ensure_plan()
         imu = self._dev(imu, "imu")
         B, T = imu.shape[0], imu.shape[1]
         fi = torch.empty(B, (T - 1) // 10, self.opt.i_f_len, device=imu.device, dtype=torch.float32)
+        if self.training:
+            names, tensors, counters = self._bn_buffers(self.Inertial_net, "Inertial_net.")
+            arr = (_lib.OdevioTensor * len(names))()
+            for i, (n, t) in enumerate(zip(names, tensors)):
+                arr[i].name, arr[i].data, arr[i].numel = n.encode(), t.data_ptr(), t.numel()
+            _lib.check(self._lib.odevio_imu_encoder_fwd_train(self._plan, imu.data_ptr(), B, T, float(self.opt.imu_dropout), arr, len(names),
+                                                              fi.data_ptr(), self.opt.i_f_len, self._stream()))
+            self._after_train_forward(counters)
+            return fi
         _lib.check(self._lib.odevio_imu_encoder_fwd(self._plan, imu.data_ptr(), B, T, fi.data_ptr(), self.opt.i_f_len,
                                                     self._stream()))
         return fi
+
+    def dropout_mask(self, seed, call, p, shape):
+        """Test hook: the factor (0 or 1 / (1 - p)) the train-mode kernels' Dropout(p) applies under draw ``call`` of ``seed``, for a
+        tensor of ``shape`` in the kernels' element order (image encoder: NHWC; inertial encoder: [pair, channel, time])."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        out = torch.empty(n, device=next(self.parameters()).device, dtype=torch.float32)
+        _lib.check(self._lib.odevio_debug_dropout(int(seed), int(call), float(p), n, out.data_ptr(), self._stream()))
+        return out.view(*shape)
 
     def set_seed(self, seed):
         """Seed of the plan's random stream (fuse_method "hard" draws its Gumbel noise from it): same seed, same masks."""

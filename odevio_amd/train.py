@@ -10,9 +10,17 @@ forward's accepted steps are replayed, their sizes held constant), ``nn.RNN`` an
 ``cat`` and ``soft`` fusion, ``odevio_fuse_hard_bwd`` the straight-through estimator of ``hard``.  Gradients reach the encoder FEATURES (fv, fi), the carried state ``hc`` and every parameter
 of ``Pose_net`` (fusion, ODEFunc, RNN, regressor) - exactly the parameters the reference's optimizer holds
 (utils/utils.py:115-119: ``Pose_net.get_other_params()`` + ``get_regressor_params()``; the encoders are not in it).
-``PoseNetTrainer`` is that optimizer step on the device: ``clip_grad_norm_`` + ``torch.optim.Adam`` as kernels
-(``odevio_grad_clip``, ``odevio_adam_step``) and ``odevio_plan_update`` to put the new parameters in front of the forward
-kernels.  The encoders' own backward is not built.
+``PoseNetTrainer`` is that optimizer step on the device: ``clip_grad_norm_`` + ``torch.optim.Adam`` (or ``SGD``) as kernels
+(``odevio_grad_clip``, ``odevio_adam_step``, ``odevio_sgd_step``) and ``odevio_plan_update`` to put the new parameters in front of
+the forward kernels.
+
+Train-mode semantics.  The reference trains under ``model.train()`` (scripts/train_model.py:219): BatchNorm with batch statistics
+and Dropout in BOTH encoders, the frozen ``Image_net`` included.  With ``model.train()`` set, ``model.image_encoder`` /
+``imu_encoder`` compute exactly that (``odevio_image_encoder_fwd_train`` / ``odevio_imu_encoder_fwd_train``: running statistics
+moved in place, masks from the model's Philox stream) and ``imu_encoder`` below back-propagates through the batch-statistics
+BatchNorm and the same masks (``odevio_imu_encoder_bwd_train``).  The IMAGE encoder's backward is not built: the reference's own
+recipe freezes it (``--freeze_encoder``, scripts/run_training.sh:24) and ``PoseNetTrainer`` refuses ``freeze_encoder = False``
+instead of silently leaving ``Image_net``'s gradients out of the clipping norm.
 """
 import ctypes
 
@@ -128,11 +136,13 @@ class _OdeRnnFunction(torch.autograd.Function):
 
 
 class _ImuEncoderFunction(torch.autograd.Function):
-    """imu [B,T,6] (+ the Inertial_net parameters) -> fi [B,(T-1)/10,i_f_len]  (InertialEncoder.forward, eval-mode BatchNorm)."""
+    """imu [B,T,6] (+ the Inertial_net parameters) -> fi [B,(T-1)/10,i_f_len]  (InertialEncoder.forward).  ``model.training``
+    decides the semantics of forward AND backward: batch-statistics BatchNorm + Dropout(opt.imu_dropout), or eval-mode BatchNorm."""
 
     @staticmethod
     def forward(ctx, model, names, imu, *params):
         imu = imu.detach().contiguous().float()
+        ctx.train_rng = model.rng_state() if model.training else None   # the three dropout draws this forward is about to make
         fi = model.imu_encoder(imu)
         ctx.model, ctx.names = model, names
         ctx.param_shapes = [tuple(p.shape) for p in params]
@@ -146,8 +156,13 @@ class _ImuEncoderFunction(torch.autograd.Function):
         g_fi = g_fi.contiguous().float()
         grads = [torch.empty(s, device=imu.device, dtype=torch.float32) for s in ctx.param_shapes]
         model._ensure_plan()
-        _lib.check(model._lib.odevio_imu_encoder_bwd(model._plan, imu.data_ptr(), imu.shape[0], imu.shape[1], g_fi.data_ptr(),
-                                                     _tensor_array(ctx.names, grads), len(grads), model._stream()))
+        if ctx.train_rng is not None:
+            _lib.check(model._lib.odevio_imu_encoder_bwd_train(model._plan, imu.data_ptr(), imu.shape[0], imu.shape[1], float(model.opt.imu_dropout),
+                                                               ctx.train_rng[0], ctx.train_rng[1], g_fi.data_ptr(),
+                                                               _tensor_array(ctx.names, grads), len(grads), model._stream()))
+        else:
+            _lib.check(model._lib.odevio_imu_encoder_bwd(model._plan, imu.data_ptr(), imu.shape[0], imu.shape[1], g_fi.data_ptr(),
+                                                         _tensor_array(ctx.names, grads), len(grads), model._stream()))
         return (None, None, None, *grads)
 
 
@@ -214,8 +229,18 @@ class PoseNetTrainer:
     their backward are not built, and their parameters are not the optimizer's).
     """
 
-    def __init__(self, model, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, gradient_clip=None, process_group=None):
+    def __init__(self, model, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, gradient_clip=None, process_group=None,
+                 optimizer=None):
         opt = model.opt
+        # what is not built is refused, not approximated (the reference's recipe sets --freeze_encoder: scripts/run_training.sh:24)
+        if not getattr(opt, "freeze_encoder", False):
+            raise NotImplementedError(
+                "PoseNetTrainer: opt.freeze_encoder is False, but the image encoder's backward is not built - the reference would then "
+                "count Image_net's gradients in clip_grad_norm_ (scripts/train_model.py:84); set freeze_encoder=True (the reference "
+                "recipe's own setting)")
+        self.optimizer = str(getattr(opt, "optimizer", "Adam") if optimizer is None else optimizer)
+        if self.optimizer not in ("Adam", "SGD"):
+            raise ValueError(f"optimizer {self.optimizer!r} not supported: Adam or SGD (utils/utils.py:120-129)")
         # data parallel over the GPUs of a node (one process per GPU): every rank steps on its own sequences, the loss is scaled by
         # 1 / world_size and the gradients are summed in ONE RCCL all-reduce before clip + Adam (odevio_amd.dist.allreduce_gradients)
         self.process_group = process_group
@@ -237,8 +262,13 @@ class PoseNetTrainer:
         for p in self.params:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise RuntimeError("PoseNetTrainer: parameters must be contiguous fp32 tensors on the GPU (model.cuda())")
-        self.exp_avg = [torch.zeros_like(p) for p in self.params]
-        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]          # SGD: the momentum buffers
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params] if self.optimizer == "Adam" else []
+        if self._world() > 1:
+            # every rank draws its OWN dropout / Gumbel noise: fold the rank into the Philox key (same seed, different streams)
+            import torch.distributed as tdist
+            seed, _ = model.rng_state()
+            model.set_seed((seed + 0x9E3779B97F4A7C15 * (tdist.get_rank(process_group) + 1)) & 0xFFFFFFFFFFFFFFFF)
         self.norm_coef = torch.zeros(2, device=self.params[0].device, dtype=torch.float32)   # {total grad norm, clip factor}
         self.steps = 0
 
@@ -280,16 +310,26 @@ class PoseNetTrainer:
         # Image_net that is Pose_net (updated below) and Inertial_net (in the norm only: the reference's optimizer does not hold it)
         extra_names = [n for n, _ in extra_pairs]
         extra = [p.grad.contiguous().float() for _, p in extra_pairs]
+        if not self.gradient_clip:
+            # the reference only steps inside `if args.gradient_clip:` (scripts/train_model.py:83-85): a falsy clip value means the
+            # gradients are dropped by the zero_grad that follows and NO update happens - reproduced, not "fixed"
+            return False
         _lib.check(lib.odevio_grad_clip(model._plan, _tensor_array(self.names + extra_names, grads + extra), len(grads) + len(extra),
                                         self.gradient_clip, self.norm_coef.data_ptr(), stream))
         self.steps += 1
-        for n, p, g, m, v in zip(self.names, self.params, grads, self.exp_avg, self.exp_avg_sq):
+        for i, (n, p, g) in enumerate(zip(self.names, self.params, grads)):
             lr = self.lr_regressor if n.startswith("Pose_net.regressor.") else self.lr
-            _lib.check(lib.odevio_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, self.betas[0],
-                                            self.betas[1], self.eps, self.weight_decay, self.steps, self.norm_coef.data_ptr(), stream))
+            if self.optimizer == "Adam":
+                _lib.check(lib.odevio_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr(), p.numel(), lr,
+                                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps, self.norm_coef.data_ptr(),
+                                                stream))
+            else:   # torch.optim.SGD(param_groups, lr=1e-4, momentum=0.9): the groups' lr_warmup overrides 1e-4, no weight decay
+                _lib.check(lib.odevio_sgd_step(p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), p.numel(), lr, 0.9, 0.0, self.steps,
+                                               self.norm_coef.data_ptr(), stream))
         # the kernels read their own layouts of these parameters (column shards, transposes): refresh them in place
         _lib.check(lib.odevio_plan_update(model._plan, _tensor_array(self.names, [p.detach() for p in self.params]), len(self.params), stream))
         model._plan_sig = model._signature()
+        return True
 
     def _world(self):
         import torch.distributed as tdist
@@ -299,22 +339,28 @@ class PoseNetTrainer:
         for p in self.model.parameters():
             p.grad = None
 
+    def accumulate(self, fv, fi, timestamps, gts, hc=None, imu=None):
+        """forward -> loss -> backward of one batch, ADDING to the gradients already in ``param.grad`` (the reference's loop calls
+        ``loss.backward()`` every batch and steps every ``grad_accumulation_steps``-th, scripts/train_model.py:78-86)."""
+        if imu is not None:
+            if fi is not None:
+                raise ValueError("PoseNetTrainer.accumulate: pass fi or imu, not both")
+            fi = imu_encoder(self.model, imu)
+        poses, h_T = pose_net(self.model, fv, fi, timestamps, hc)
+        loss = pose_loss(poses, gts)
+        world = self._world()
+        (loss if world == 1 else loss * (1.0 / world)).backward()
+        return loss.detach(), poses.detach(), h_T.detach()
+
     def step(self, fv, fi, timestamps, gts, hc=None, imu=None):
         """One training step on a batch of features; returns (loss, poses, h_T) - ``loss`` a device scalar
         (``float(loss)`` synchronises, like the reference's ``pose_loss.item()``).  With ``imu`` [B,T,6] instead of ``fi``
         the inertial encoder is part of the graph: its gradients enter the clipping norm as in the reference's step."""
         self.zero_all_grads()
-        if imu is not None:
-            if fi is not None:
-                raise ValueError("PoseNetTrainer.step: pass fi or imu, not both")
-            fi = imu_encoder(self.model, imu)
-        poses, h_T = pose_net(self.model, fv, fi, timestamps, hc)
-        loss = pose_loss(poses, gts)
-        world = self._world()
-        (loss if world == 1 else loss * (1.0 / world)).backward()   # the sum over ranks in apply_gradients is then the mean
+        out = self.accumulate(fv, fi, timestamps, gts, hc=hc, imu=imu)
         self.apply_gradients()
         self.zero_all_grads()
-        return loss.detach(), poses.detach(), h_T.detach()
+        return out
 
     @property
     def grad_norm(self):
@@ -324,20 +370,28 @@ class PoseNetTrainer:
 
 def train_epoch(model, trainer, loader, log=None, log_every=20):
     """One epoch of the reference's ``train()`` (scripts/train_model.py:48-95) on libodevio: ``loader`` yields
-    ``(imgs [B,S,3,H,W], imus [B,10(S-1)+1,6], gts [B,S-1,6], timestamps [B,S], folder)`` like the reference's ``DataLoader``;
-    every batch is one ``PoseNetTrainer.step`` with the image features from ``model.image_encoder`` (the recipe's frozen
-    ``Image_net``; eval-mode BatchNorm, no dropout - see the module docstring) and the inertial encoder inside the graph.
+    ``(imgs [B,S,3,H,W], imus [B,10(S-1)+1,6], gts [B,S-1,6], timestamps [B,S], folder)`` like the reference's ``DataLoader``.
+    Like the reference's epoch loop (:219) the model is put in ``train()``: both encoders run with batch-statistics BatchNorm and
+    Dropout (the frozen ``Image_net`` under ``no_grad``, the inertial encoder inside the graph); gradients accumulate over
+    ``opt.grad_accumulation_steps`` batches (and the last batch) before clip + step (:82-86); ``opt.optimizer`` picks Adam or SGD.
     Returns the mean pose loss like the reference.  ``log(message)`` receives the reference's per-iteration line."""
     losses = []
-    n = len(loader) if hasattr(loader, "__len__") else None
-    for i, (imgs, imus, gts, timestamps, _folder) in enumerate(loader):
+    model.train()
+    accum = max(1, int(getattr(model.opt, "grad_accumulation_steps", 1)))
+    batches = list(loader) if not hasattr(loader, "__len__") else loader
+    n = len(batches)
+    trainer.zero_all_grads()
+    for i, (imgs, imus, gts, timestamps, _folder) in enumerate(batches):
         dev = next(model.parameters()).device
         imgs, imus = imgs.to(dev).float(), imus.to(dev).float()
         gts, timestamps = gts.to(dev).float(), timestamps.to(dev).float()
         with torch.no_grad():
             fv = model.image_encoder(imgs)
-        loss, _, _ = trainer.step(fv, None, timestamps, gts, imu=imus)
+        loss, _, _ = trainer.accumulate(fv, None, timestamps, gts, imu=imus)
+        if (i + 1) % accum == 0 or (i + 1) == n:
+            trainer.apply_gradients()
+            trainer.zero_all_grads()
         if log is not None and i % log_every == 0:
-            log(f"iters: {i + 1}/{n if n is not None else '?'}, pose loss: {float(loss):.6f}, grad norm: {float(trainer.grad_norm):.4f}")
+            log(f"iters: {i + 1}/{n}, pose loss: {float(loss):.6f}, grad norm: {float(trainer.grad_norm):.4f}")
         losses.append(loss)
     return float(torch.stack(losses).mean()) if losses else float("nan")

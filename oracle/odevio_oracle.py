@@ -7,8 +7,9 @@ imports it and fails loudly when the HIP library is missing.
 What it restates (every function cites the reference file:line it follows; paths are relative to
 the reference checkout, mc1017/ODE-VIO):
 
-* ``image_encoder``    - src/models/Encoder.py:97-122 (+ ``conv`` block :8-22)
-* ``inertial_encoder`` - src/models/Encoder.py:60-74
+* ``image_encoder``    - src/models/Encoder.py:97-122 (+ ``conv`` block :8-22); with ``train=`` the model.train() semantics the
+                         reference trains under (scripts/train_model.py:219): batch-statistics BatchNorm + Dropout for given masks
+* ``inertial_encoder`` - src/models/Encoder.py:60-74 (same ``train=`` switch)
 * ``fuse``             - src/models/FusionModule.py:17-23 (``cat`` and ``soft``)
 * ``ode_func``         - src/models/ODEFunc.py:9-15,38-39
 * ``evolve_state``     - src/models/PoseODERNN.py:70-75 + torchode 0.2.0 (NOT in the checkout)
@@ -55,24 +56,51 @@ def _sd(sd, dtype):
 # ----------------------------------------------------------------------------------------------
 # encoders
 # ----------------------------------------------------------------------------------------------
-def conv_block(sd, prefix, x, k, stride):
-    """Conv2d(bias=False, pad=(k-1)//2) -> BN2d(eval) -> LeakyReLU(0.1); Encoder.py:8-22 (eval: dropout = id)."""
+IMAGE_DROPOUT = (0.2,) * 8 + (0.5,)  # Encoder.py:82-90: Dropout(0.2) after conv1 .. conv5_1, Dropout(0.5) after conv6
+BN_MOMENTUM = 0.1  # nn.BatchNorm default
+
+
+def _bn(sd, q, y, train):
+    """BatchNorm in eval mode (running statistics) or, with ``train`` = a dict that collects the updated buffers, exactly what
+    the module does under ``model.train()``: F.batch_norm(training=True, momentum=0.1) on CLONES of the running statistics
+    (batch statistics normalise, the clones receive torch's own update) and num_batches_tracked + 1."""
+    if train is None:
+        return F_.batch_norm(y, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"], False, 0.0, BN_EPS)
+    rm, rv = sd[q + ".running_mean"].clone(), sd[q + ".running_var"].clone()
+    out = F_.batch_norm(y, rm, rv, sd[q + ".weight"], sd[q + ".bias"], True, BN_MOMENTUM, BN_EPS)
+    train[q + ".running_mean"], train[q + ".running_var"] = rm, rv
+    if q + ".num_batches_tracked" in sd:
+        train[q + ".num_batches_tracked"] = sd[q + ".num_batches_tracked"] + 1
+    return out
+
+
+def _dropout(x, mask, p):
+    """nn.Dropout(p) in train mode for a GIVEN keep mask (1 = kept): x * mask / (1 - p).  torch draws the mask from its own
+    generator (no bit-level parity possible); the GPU tests hand the device's mask in (odevio_debug_dropout)."""
+    if mask is None:
+        return x
+    return x * (mask.to(x.dtype) * (1.0 / (1.0 - p)))
+
+
+def conv_block(sd, prefix, x, k, stride, train=None, mask=None, p_drop=0.0):
+    """Conv2d(bias=False, pad=(k-1)//2) -> BN2d -> LeakyReLU(0.1) -> Dropout; Encoder.py:8-22.  eval (train=None): running
+    statistics, dropout = id.  train mode: batch statistics (+ the buffers' update collected in ``train``), dropout with ``mask``."""
     y = F_.conv2d(x, sd[prefix + ".0.weight"], None, stride=stride, padding=(k - 1) // 2)
-    y = F_.batch_norm(y, sd[prefix + ".1.running_mean"], sd[prefix + ".1.running_var"],
-                      sd[prefix + ".1.weight"], sd[prefix + ".1.bias"], False, 0.0, BN_EPS)
-    return F_.leaky_relu(y, 0.1)
+    y = F_.leaky_relu(_bn(sd, prefix + ".1", y, train), 0.1)
+    return _dropout(y, mask, p_drop) if train is not None else y
 
 
-def image_encoder(sd, img, dtype=torch.float32, return_intermediate=False):
-    """Encoder.py:97-122.  img [B,S,3,H,W] -> fv [B,S-1,v_f_len]."""
+def image_encoder(sd, img, dtype=torch.float32, return_intermediate=False, train=None, masks=None):
+    """Encoder.py:97-122.  img [B,S,3,H,W] -> fv [B,S-1,v_f_len].  ``train`` (a dict) switches to model.train() semantics:
+    batch-statistics BatchNorm, the updated buffers returned in the dict, Dropout with the given ``masks`` (9 NCHW keep masks)."""
     sd = _sd(sd, dtype)
     img = img.to(dtype)
     v = torch.cat((img[:, :-1], img[:, 1:]), dim=2)  # :101 pair concat on the channel axis
     B, P = v.shape[0], v.shape[1]
     x = v.reshape(B * P, v.shape[2], v.shape[3], v.shape[4])
     inter = {}
-    for name, k, s in IMAGE_CONVS:
-        x = conv_block(sd, "Image_net." + name, x, k, s)
+    for i, (name, k, s) in enumerate(IMAGE_CONVS):
+        x = conv_block(sd, "Image_net." + name, x, k, s, train, None if masks is None else masks[i], IMAGE_DROPOUT[i])
         if return_intermediate:
             inter[name] = x
     flat = x.reshape(B, P, -1)  # :110 flatten in (C,H,W) order
@@ -80,21 +108,22 @@ def image_encoder(sd, img, dtype=torch.float32, return_intermediate=False):
     return (fv, inter) if return_intermediate else fv
 
 
-def inertial_encoder(sd, imu, dtype=torch.float32):
-    """Encoder.py:60-74.  imu [B,T,6] -> fi [B,(T-1)//10,i_f_len]; windows of 11 samples, stride 10."""
+def inertial_encoder(sd, imu, dtype=torch.float32, train=None, masks=None, p_drop=0.0):
+    """Encoder.py:60-74.  imu [B,T,6] -> fi [B,(T-1)//10,i_f_len]; windows of 11 samples, stride 10.  ``train`` / ``masks``
+    (3 keep masks [B*P, C, 11]) / ``p_drop`` = opt.imu_dropout: model.train() semantics as in image_encoder."""
     sd = _sd(sd, dtype)
     imu = imu.to(dtype)
     B = imu.shape[0]
     n_pairs = (imu.shape[1] - 1) // 10
     win = torch.stack([imu[:, 10 * i:10 * i + 11, :] for i in range(n_pairs)], dim=1)  # [B,P,11,6]
     x = win.reshape(B * n_pairs, 11, 6).permute(0, 2, 1)  # [BP,6,11]
-    for idx in (0, 4, 8):
+    for j, idx in enumerate((0, 4, 8)):
         p = f"Inertial_net.encoder_conv.{idx}"
         q = f"Inertial_net.encoder_conv.{idx + 1}"
         x = F_.conv1d(x, sd[p + ".weight"], sd[p + ".bias"], padding=1)
-        x = F_.batch_norm(x, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"],
-                          sd[q + ".bias"], False, 0.0, BN_EPS)
-        x = F_.leaky_relu(x, 0.1)
+        x = F_.leaky_relu(_bn(sd, q, x, train), 0.1)
+        if train is not None:
+            x = _dropout(x, None if masks is None else masks[j], p_drop)
     out = F_.linear(x.reshape(x.shape[0], -1), sd["Inertial_net.proj.weight"], sd["Inertial_net.proj.bias"])
     return out.reshape(B, n_pairs, -1)
 

@@ -40,3 +40,18 @@ def gumbel_pairs(seed, call, n):
     u = ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
     g = -np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
     return g.reshape(n, 2)
+
+
+def dropout_factors(seed, call, p, n):
+    """What the device's train-mode Dropout(p) multiplies each of n elements by under draw `call` of `seed` (odevio_amd/csrc/philox.h):
+    element e uses word e % 4 of counter block (e // 4 lo, e // 4 hi, call lo, call hi); kept iff that word >= floor(p * 2^32);
+    kept elements are scaled by float32(1) / (float32(1) - float32(p)).  out [n] float32."""
+    if p <= 0:
+        return np.ones(n, dtype=np.float32)
+    i = np.arange((n + 3) // 4, dtype=np.uint64)
+    ctr = np.stack([i & MASK, i >> np.uint64(32), np.full_like(i, call & 0xFFFFFFFF), np.full_like(i, (call >> 32) & 0xFFFFFFFF)], axis=-1)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    bits = philox4x32_10(ctr, key).reshape(-1)[:n]
+    thr = np.uint32(min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return np.where(bits >= thr, scale, np.float32(0.0)).astype(np.float32)

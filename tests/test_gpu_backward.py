@@ -162,7 +162,7 @@ def _torch_reference_training(sd, opt, names, batches, lr, weight_decay, clip, e
     (dict(model_type="rnn", ode_rnn_type="gru"), 5.0),
 ])
 def test_pose_net_trainer_follows_torch_adam_on_the_oracle(cfg, clip):
-    opt = default_opt(img_h=64, img_w=128, **cfg)
+    opt = default_opt(img_h=64, img_w=128, freeze_encoder=True, **cfg)
     model, sd = make_model(opt, seed=81)
     B, P = 3, 4
     g = torch.Generator().manual_seed(9)
@@ -221,7 +221,7 @@ def test_pose_net_trainer_follows_torch_adam_on_the_oracle(cfg, clip):
 
 
 def test_training_reduces_the_loss_on_a_fixed_batch():
-    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", freeze_encoder=True)
     model, _ = make_model(opt, seed=82)
     g = torch.Generator().manual_seed(10)
     fv, fi = torch.randn(4, 5, 512, generator=g).cuda(), torch.randn(4, 5, 256, generator=g).cuda()
@@ -257,7 +257,7 @@ def test_inertial_encoder_backward_matches_autograd_through_the_oracle():
 def test_trainer_with_the_inertial_encoder_in_the_graph():
     """The reference's recipe freezes Image_net only: Inertial_net's gradients exist and count in clip_grad_norm_(model.parameters()),
     while the optimizer holds Pose_net alone (utils/utils.py:116-119)."""
-    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", freeze_encoder=True)
     model, sd = make_model(opt, seed=84)
     B, P = 3, 4
     g = torch.Generator().manual_seed(12)
@@ -301,8 +301,9 @@ def test_trainer_with_the_inertial_encoder_in_the_graph():
 
 def test_train_epoch_runs_the_reference_loop_end_to_end():
     """train.train_epoch = scripts/train_model.py:48-95 on the device path: frames and IMU samples in, encoders, pose net,
-    loss, backward, clip, Adam per batch.  A fixed pair of batches, several epochs: the loss goes down, nothing fails."""
-    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4")
+    loss, backward, clip, Adam per batch - under model.train() like the reference's epoch loop (:219): batch-statistics BatchNorm and
+    Dropout in both encoders.  A fixed pair of batches, several epochs: the loss goes down, nothing fails."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", freeze_encoder=True)
     model, _ = make_model(opt, seed=85)
     batches = []
     for k in range(2):
@@ -314,8 +315,14 @@ def test_train_epoch_runs_the_reference_loop_end_to_end():
     lines = []
     means = [train.train_epoch(model, trainer, batches, log=lines.append, log_every=1) for _ in range(6)]
     model.check()
-    assert all(m == m for m in means) and means[-1] < 0.8 * means[0], means
+    assert model.training and all(m == m for m in means) and means[-1] < 0.9 * means[0], means
     assert len(lines) == 12 and "pose loss" in lines[0]
+    assert int(model.Image_net.conv1[1].num_batches_tracked) == 1 + 12          # the constructor's dummy forward + 12 train-mode batches
+    model.eval()
+    img, imu, ts = batches[0][0], batches[0][1], batches[0][3]
+    poses, _ = model(img.cuda(), imu.cuda(), ts.cuda())                          # eval afterwards folds the MOVED running statistics
+    ref, _ = oc.deepvio_forward({k: v.detach().cpu() for k, v in model.state_dict().items()}, img, imu, ts, None, opt)
+    assert oc.rel_err(poses, ref) < 1e-4
 
 
 def test_hard_fusion_straight_through_backward_with_the_same_noise():

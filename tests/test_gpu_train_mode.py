@@ -1,0 +1,257 @@
+"""GPU parity of the model.train() semantics.
+
+The reference trains under ``model.train()`` (scripts/train_model.py:219, forward at :69): every BatchNorm of both encoders - the
+frozen Image_net's too - normalises with batch statistics and moves its running statistics, every Dropout is on
+(src/models/Encoder.py:8-22,43-57,82-90).  Dropout draws from torch's generator in the reference, so the device path (Philox) can
+never be bit-equal to it: parity is checked by handing the DEVICE's masks to the oracle, whose train-mode arithmetic is itself pinned
+against the real reference modules with the masks THEY drew (tests/test_oracle_golden.py, tests/golden/train_mode.npz).
+"""
+import numpy as np
+import pytest
+import torch
+
+from odevio_amd import default_opt, synth, train
+from oracle import odevio_oracle as oc
+from oracle import philox as ph
+
+from test_gpu_parity import assert_close, make_model
+
+pytestmark = pytest.mark.gpu
+
+IMAGE_P = oc.IMAGE_DROPOUT
+
+
+def _image_masks(model, opt, seed, call0, n_pairs):
+    """Keep masks (NCHW, 1 = kept) of the 9 blocks for draws call0 .. call0+8, from the device generator."""
+    from odevio_amd import weights
+    masks, h, w = [], opt.img_h, opt.img_w
+    for i, (_, _, cout, k, s) in enumerate(weights.IMAGE_CONVS):
+        h, w = weights.conv_out(h, k, s), weights.conv_out(w, k, s)
+        f = model.dropout_mask(seed, call0 + i, IMAGE_P[i], (n_pairs, h, w, cout)).cpu()      # device order: NHWC
+        masks.append((f != 0).float().permute(0, 3, 1, 2).contiguous())
+    return masks
+
+
+def _imu_masks(model, seed, call0, n_pairs, p):
+    return [(model.dropout_mask(seed, call0 + j, p, (n_pairs, c, 11)).cpu() != 0).float() for j, c in enumerate((64, 128, 256))]
+
+
+def test_dropout_generator_matches_the_philox_restatement():
+    opt = default_opt(img_h=64, img_w=128)
+    model, _ = make_model(opt, seed=70)
+    for seed, call, p, n in ((0, 0, 0.2, 1003), (5, 7, 0.5, 4096), (0xABCDEF0123456789, (1 << 34) + 1, 0.3, 777), (1, 2, 0.0, 64)):
+        dev = model.dropout_mask(seed, call, p, (n,)).cpu().numpy()
+        ref = ph.dropout_factors(seed, call, p, n)
+        assert np.array_equal(dev, ref), (seed, call, p)
+    keep = float((model.dropout_mask(3, 0, 0.2, (1 << 20,)) != 0).float().mean())
+    assert abs(keep - 0.8) < 2e-3, keep
+
+
+def test_image_encoder_train_mode_three_steps():
+    """ImageEncoder.forward under train(): fv to 1e-4 of the oracle fed the device's masks, for three consecutive steps, and the
+    running statistics / num_batches_tracked afterwards equal torch's own update of the same buffers."""
+    opt = default_opt(img_h=64, img_w=128)
+    model, sd = make_model(opt, seed=71)
+    model.train()
+    model.set_seed(21)
+    B, S = 3, 3
+    P = B * (S - 1)
+    ref_sd = dict(sd)
+    for step in range(3):
+        img = synth.images(B, S, 64, 128, seed=80 + step)
+        seed, call0 = model.rng_state()
+        assert (seed, call0) == (21, 9 * step)
+        fv = model.image_encoder(img.cuda())
+        model.check()
+        new = {}
+        ref = oc.image_encoder(ref_sd, img, train=new, masks=_image_masks(model, opt, seed, call0, P))
+        assert_close(fv, ref, what=f"fv, train-mode step {step}")
+        ref_sd = {**ref_sd, **new}
+    now = model.state_dict()
+    for k, v in ref_sd.items():
+        if k.startswith("Image_net.") and ("running" in k or "num_batches" in k):
+            if "num_batches" in k:
+                assert int(now[k]) == int(v) == 4, k
+            else:
+                assert oc.rel_err(now[k], v) < 1e-5, (k, oc.rel_err(now[k], v))
+    # eval mode afterwards: the plan folds the MOVED statistics (and matches the oracle on them), not the ones it was built with
+    model.eval()
+    fv_eval = model.image_encoder(img.cuda())
+    assert_close(fv_eval, oc.image_encoder(ref_sd, img), what="fv, eval mode after training")
+    assert oc.rel_err(fv_eval, oc.image_encoder(sd, img)) > 1e-3
+
+
+def test_image_encoder_train_mode_full_size_batch():
+    """The bench batch's shape in train mode (16 x 11 frames of 256 x 512: 5.2 M pixels per channel in conv1's statistics; split-K
+    layers with the identity epilogue): finite, deterministic per seed, different per draw, and sequences 0..1 agree with the oracle
+    run on the SAME batch statistics (the oracle walks the whole batch: BatchNorm couples the pairs)."""
+    opt = default_opt()
+    model, sd = make_model(opt, seed=72, randomize=False)
+    model.train()
+    B, S = 4, 3                       # 8 pairs at full resolution: the oracle's train-mode pass stays at seconds
+    img = synth.images(B, S, 256, 512, seed=90)
+    model.set_seed(5)
+    fv = model.image_encoder(img.cuda())
+    model.check()
+    ref = oc.image_encoder(sd, img, train={}, masks=_image_masks(model, opt, 5, 0, B * (S - 1)))
+    assert_close(fv, ref, what="fv, train mode at 256x512")
+    model.set_seed(5)
+    assert torch.equal(model.image_encoder(img.cuda()), fv)
+    assert not torch.equal(model.image_encoder(img.cuda()), fv)
+    img16 = synth.images(16, 11, 256, 512, seed=91).cuda()
+    fv16 = model.image_encoder(img16)
+    model.check()
+    assert fv16.shape == (16, 10, 512) and torch.isfinite(fv16).all()
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_inertial_encoder_train_mode_forward_and_backward(p):
+    """InertialEncoder under train(): forward (fi, running statistics) and every parameter gradient against autograd through the
+    oracle with the device's masks - the batch-statistics BatchNorm backward and the masks of the same three draws."""
+    opt = default_opt(img_h=64, img_w=128, imu_dropout=p)
+    model, sd = make_model(opt, seed=73)
+    model.train()
+    model.set_seed(9)
+    B, T = 3, 41
+    n_pairs = B * 4
+    imu = synth.imu(B, 5, seed=13)
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(B, 4, 256, generator=g)
+    names = train.imu_param_names()
+    fi = train.imu_encoder(model, imu.cuda())
+    (fi * w.cuda()).sum().backward()
+    model.check()
+    assert model.rng_state() == (9, 3)
+    leaves = {k: (v.clone().double().requires_grad_(k in names) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    new = {}
+    ref = oc.inertial_encoder(leaves, imu, dtype=torch.float64, train=new, masks=_imu_masks(model, 9, 0, n_pairs, p), p_drop=p)
+    (ref * w.double()).sum().backward()
+    assert_close(fi, ref, what="fi (train mode)")
+    params = dict(model.named_parameters())
+    for n in names:
+        got, want = params[n].grad, leaves[n].grad
+        scale = float(want.abs().max())
+        if n.endswith(("0.bias", "4.bias", "8.bias")):
+            # a conv bias in front of a batch-statistics BatchNorm has a zero gradient in exact arithmetic: both sides hold rounding noise
+            assert float(got.abs().max()) < 1e-4 * float(leaves[n.replace(".bias", ".weight")].grad.abs().max()) + 1e-6, n
+            continue
+        assert float((got.cpu().double() - want).abs().max()) <= 1e-3 * scale, (n, oc.rel_err(got, want))
+    now = model.state_dict()
+    for k, v in new.items():
+        if "num_batches" in k:
+            assert int(now[k]) == int(v)
+        else:
+            assert oc.rel_err(now[k], v.float()) < 1e-5, k
+
+
+def test_deepvio_forward_in_train_mode_is_the_reference_training_forward():
+    """model.train(); model(img, imu, ts) = what scripts/train_model.py:69 computes: train-mode encoders, then the pose net
+    (which has no train-mode difference: rnn_dropout_out is unused, PoseODERNN.py:43-47)."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", imu_dropout=0.2)
+    model, sd = make_model(opt, seed=74)
+    model.train()
+    model.set_seed(31)
+    img, imu, ts = synth.batch(3, 4, 64, 128, seed=23)
+    with torch.no_grad():
+        poses, h = model(img.cuda(), imu.cuda(), ts.cuda())
+    model.check()
+    assert model.rng_state() == (31, 12)                                     # 9 image-encoder draws, then 3 inertial-encoder draws
+    fv = oc.image_encoder(sd, img, train={}, masks=_image_masks(model, opt, 31, 0, 9))
+    fi = oc.inertial_encoder(sd, imu, train={}, masks=_imu_masks(model, 31, 9, 9, 0.2), p_drop=0.2)
+    ref_p, ref_h = oc.pose_ode_rnn(sd, fv, fi, ts, None, opt)
+    assert_close(poses, ref_p, what="poses (train-mode forward)")
+    assert_close(h, ref_h, what="h_T (train-mode forward)")
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 64, 128, 3, dtype=torch.uint8, device="cuda"), imu[:1, :21].cuda(), ts[:1, :3].cuda())
+
+
+def _loss(poses, gts):
+    return 100 * torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3]) + torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:])
+
+
+@pytest.mark.parametrize("optimizer,accum", [("Adam", 1), ("SGD", 1), ("Adam", 2)])
+def test_train_epoch_follows_torch_with_batchnorm_in_train_mode(optimizer, accum):
+    """train_epoch against the reference's loop restated on the oracle (scripts/train_model.py:48-95 under model.train()): frozen
+    Image_net in train mode, the inertial encoder in the graph with batch-statistics BatchNorm + Dropout (device masks handed over),
+    clip_grad_norm_ over Pose_net + Inertial_net, torch.optim.Adam / SGD over Pose_net, gradient accumulation.  Loss trajectory,
+    gradient norms and parameters after the epoch."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", freeze_encoder=True, imu_dropout=0.1, optimizer=optimizer,
+                      grad_accumulation_steps=accum, gradient_clip=0.05 if optimizer == "Adam" else 5.0, lr_warmup=1e-4)
+    model, sd = make_model(opt, seed=75)
+    model.set_seed(77)
+    B, S = 3, 4
+    P = B * (S - 1)
+    scale = torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    batches = []
+    for k in range(4):
+        img, imu, ts = synth.batch(B, S, 64, 128, seed=60 + k)
+        g = torch.Generator().manual_seed(70 + k)
+        batches.append((img, imu, torch.randn(B, S - 1, 6, generator=g) * scale, ts, "synthetic"))
+    trainer = train.PoseNetTrainer(model)
+    losses, norms = [], []
+    mean = train.train_epoch(model, trainer, batches, log=lambda m: (losses.append(float(m.split("pose loss: ")[1].split(",")[0])),
+                                                                     norms.append(float(m.split("grad norm: ")[1]))), log_every=1)
+    model.check()
+    # ---- the same epoch in PyTorch on the oracle, fed the device's masks (12 draws per batch: 9 image blocks, 3 inertial blocks)
+    inames = train.imu_param_names()
+    leaves = {k: (v.clone().float() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    params = [leaves[n].requires_grad_(True) for n in trainer.names]
+    iparams = [leaves[n].requires_grad_(True) for n in inames]
+    if optimizer == "Adam":
+        optim = torch.optim.Adam(params, lr=opt.lr_warmup, betas=(0.9, 0.999), eps=1e-8, weight_decay=opt.weight_decay)
+    else:
+        optim = torch.optim.SGD(params, lr=opt.lr_warmup, momentum=0.9)
+    ref_losses, ref_norms = [], []
+    optim.zero_grad()
+    for i, (img, imu, gts, ts, _) in enumerate(batches):
+        new = {}
+        with torch.no_grad():
+            fv = oc.image_encoder(leaves, img, train=new, masks=_image_masks(model, opt, 77, 12 * i, P))
+        fi = oc.inertial_encoder(leaves, imu, train=new, masks=_imu_masks(model, 77, 12 * i + 9, P, 0.1), p_drop=0.1)
+        poses, _ = oc.pose_ode_rnn(leaves, fv, fi, ts, None, opt)
+        loss = _loss(poses, gts)
+        loss.backward()
+        for k, v in new.items():
+            leaves[k] = v
+        if (i + 1) % accum == 0 or i + 1 == len(batches):
+            ref_norms.append(float(torch.nn.utils.clip_grad_norm_(params + iparams, max_norm=opt.gradient_clip)))
+            optim.step()
+            optim.zero_grad()
+            for q in iparams:
+                q.grad = None
+        ref_losses.append(float(loss.detach()))
+    assert len(losses) == 4 and abs(mean - sum(ref_losses) / 4) <= 3e-4 * abs(mean)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 3e-4 * abs(b) + 1e-6, (losses, ref_losses)
+    dev_norms = [norms[i] for i in range(len(batches)) if (i + 1) % accum == 0 or i + 1 == len(batches)]
+    for a, b in zip(dev_norms, ref_norms):
+        assert abs(a - b) <= 3e-3 * b, (dev_norms, ref_norms)
+    lr = opt.lr_warmup
+    for n, p in zip(trainer.names, trainer.params):
+        d = (p.detach().cpu() - leaves[n].detach()).abs()
+        if optimizer == "Adam":
+            assert float(d.max()) <= 1.0 * lr * len(ref_norms), n
+            assert float((d > 0.03 * lr).float().mean()) < 3e-3, n
+        else:
+            moved = float((leaves[n].detach() - sd[n]).abs().max())
+            assert float(d.max()) <= 2e-3 * moved + 1e-9, (n, float(d.max()), moved)
+    now = model.state_dict()
+    for k in now:
+        if "running" in k:
+            assert oc.rel_err(now[k], leaves[k]) < 2e-5, k
+
+
+def test_a_falsy_gradient_clip_means_no_update_like_the_reference():
+    """scripts/train_model.py:83-86: `if args.gradient_clip: clip; optimizer.step()` - with gradient_clip = 0 the gradients are
+    zeroed and nothing is updated."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", freeze_encoder=True, gradient_clip=0)
+    model, _ = make_model(opt, seed=76)
+    g = torch.Generator().manual_seed(10)
+    fv, fi = torch.randn(2, 3, 512, generator=g).cuda(), torch.randn(2, 3, 256, generator=g).cuda()
+    ts, gts = synth.timestamps(2, 4, seed=3).cuda(), torch.randn(2, 3, 6, generator=g).cuda()
+    trainer = train.PoseNetTrainer(model)
+    before = [p.detach().clone() for p in trainer.params]
+    trainer.step(fv, fi, ts, gts)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, trainer.params)) and trainer.steps == 0
+    with pytest.raises(NotImplementedError):
+        train.PoseNetTrainer(make_model(default_opt(img_h=64, img_w=128), seed=76)[0])           # freeze_encoder = False: refused

@@ -107,3 +107,57 @@ def test_pose_rnn_skeleton(golden_dir, rnn_type, L, method):
     p2, h2 = oc.pose_rnn(sd, fv.flip(0), fi.flip(0), ts, h1, opt)  # carried hidden state, layout [L,B,F]
     close(p2, g[key + "_pose2"])
     close(h2, g[key + "_h2"])
+
+
+# ------------------------------------------------------------------------------------------------
+# model.train() semantics of the encoders (scripts/train_model.py:219) against the REAL modules in train mode
+# (tests/golden/train_mode.npz, made by oracle/gen_golden_train.py: the dropout masks the modules drew are part of the fixture)
+# ------------------------------------------------------------------------------------------------
+def _unpack(g, key):
+    shape = tuple(int(x) for x in g[key + "_shape"])
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.unpackbits(g[key])[:n].reshape(shape).astype(np.float32))
+
+
+def test_image_encoder_train_mode(golden_dir):
+    g = load(golden_dir, "train_mode.npz")
+    H, W, B, S = int(g["img_H"]), int(g["img_W"]), int(g["img_B"]), int(g["img_S"])
+    opt = default_opt(img_h=H, img_w=W)
+    sd = weights.make_state_dict(opt, seed=int(g["img_wseed"]), randomize_stats=True)
+    for step in range(2):                      # two consecutive steps: the second normalises with fresh batch statistics
+        img = synth.images(B, S, H, W, seed=40 + step)   # and moves the buffers the first one left behind
+        assert abs(float(img.double().sum()) - float(g[f"img{step}_sum"])) < 1e-6
+        masks = [_unpack(g, f"img{step}_mask{i}") for i in range(9)]
+        kept = [float(m.mean()) for m in masks]
+        assert all(abs(k - 0.8) < 0.02 for k in kept[:8]) and abs(kept[8] - 0.5) < 0.05, kept   # Dropout(0.2) x 8, Dropout(0.5)
+        new = {}
+        fv = oc.image_encoder(sd, img, train=new, masks=masks)
+        close(fv, g[f"img{step}_fv"])
+        for k, v in new.items():
+            ref = g[f"img{step}_buf_" + k[len("Image_net."):]]
+            if "num_batches" in k:
+                assert int(v) == int(ref) == step + 2           # the constructor's dummy forward counted once (Encoder.py:92-93)
+            else:
+                close(v, ref, tol=1e-5)
+        sd = {**sd, **new}
+    # eval mode afterwards reads the moved buffers: not what it computed before training
+    assert oc.rel_err(oc.image_encoder(sd, img), oc.image_encoder(weights.make_state_dict(opt, seed=int(g["img_wseed"]), randomize_stats=True), img)) > 1e-3
+
+
+def test_inertial_encoder_train_mode(golden_dir):
+    g = load(golden_dir, "train_mode.npz")
+    p = float(g["imu_p"])
+    opt = default_opt(imu_dropout=p)
+    sd = weights.make_state_dict(opt, seed=int(g["imu_wseed"]), randomize_stats=True)
+    imu = synth.imu(3, 5, seed=9)
+    assert abs(float(imu.double().sum()) - float(g["imu_sum"])) < 1e-6
+    masks = [_unpack(g, f"imu_mask{i}") for i in range(3)]
+    new = {}
+    fi = oc.inertial_encoder(sd, imu, train=new, masks=masks, p_drop=p)
+    close(fi, g["imu_fi"])
+    for k, v in new.items():
+        ref = g["imu_buf_" + k[len("Inertial_net."):]]
+        if "num_batches" in k:
+            assert int(v) == int(ref)
+        else:
+            close(v, ref, tol=1e-5)

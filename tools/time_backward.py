@@ -9,7 +9,7 @@ from odevio_amd import DeepVIO, default_opt, synth, train  # noqa: E402
 
 solver = sys.argv[1] if len(sys.argv) > 1 else "rk4"
 rnn = sys.argv[2] if len(sys.argv) > 2 else "rnn"
-opt = default_opt(img_h=64, img_w=128, ode_solver=solver, ode_rnn_type=rnn)
+opt = default_opt(img_h=64, img_w=128, ode_solver=solver, ode_rnn_type=rnn, freeze_encoder=True)
 m = DeepVIO(opt, seed=0).cuda()
 B, P = 16, 10
 g = torch.Generator().manual_seed(0)
