@@ -249,10 +249,7 @@ def run_cde(args, rank, world, dist):
     sync()
     elapsed = time.perf_counter() - t0
     model.check()
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, ranks = rank_report(dist, world, elapsed, args.steps, torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
     if rank == 0:
         # ---- the dominant kernel: one vector-field evaluation on an odd piece = one pass over the [H*(H+1), H] fp32 last
         # layer.  Timed with HIP events on the launch stream (torch's current stream is the one the library launches on).
@@ -282,6 +279,7 @@ def run_cde(args, rank, world, dist):
                                    f"t = {args.cde_t0:.2f} .. {args.cde_t0 + 1.0:.2f} s (piece 1 of the rectilinear control path: every feature "
                                    "channel moves, each evaluation streams the whole last layer), fp32 (BASELINE configs[4] shape)",
                        "sequences_per_gpu": B, "seq_len": S, "cde_solver": "dopri5", "sharding": f"sequences x{world}"},
+            "ranks": ranks,
             "solver": {"steps_attempted": n_steps, "steps_accepted": n_acc,
                        "note": "one step size for the whole batch (torchdiffeq); controller on the device, the host reads `done` once per batch of attempts"},
             "roofline": {"kernel": f"cde_stream_kernel<{Hc}> (CDEFunc last layer + tanh + contraction with dX/dt)", "bound": "hbm",
@@ -324,6 +322,77 @@ def cde_cpu_baseline(opt, sd, obs, z, n_steps, budget_s=20.0):
                       f"window = {n_evals} evaluations ({n_steps} dopri5 steps)"}
 
 
+def rank_report(dist, world, elapsed, steps, device):
+    """What makes a multi-rank line self-checking: the timed region's MAX over ranks (the contract's clock) plus, gathered over the
+    SAME process group the step's all-gather uses, every rank's own time and device, and `collective_world` = the sum of ones over a
+    real 1-element all-reduce (= the number of ranks the collective backend actually connected, not an environment variable).
+    Returns (elapsed_max, dict)."""
+    name = torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu (stub)"
+    if world == 1:
+        return elapsed, {"collective_world": 1, "backend": None, "per_rank_ms_per_step": [round(1e3 * elapsed / steps, 4)], "devices": [name]}
+    one = torch.ones(1, device=device, dtype=torch.float32)
+    dist.all_reduce(one)                                                     # RCCL (gloo in the CPU rehearsal)
+    mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    every = torch.empty(world, device=device, dtype=torch.float64)
+    dist.all_gather_into_tensor(every, mine)
+    names = [None] * world
+    dist.all_gather_object(names, name)
+    per_rank = [float(x) for x in every.cpu()]
+    return max(per_rank), {"collective_world": int(round(float(one.item()))), "backend": dist.get_backend(),
+                           "per_rank_ms_per_step": [round(1e3 * x / steps, 4) for x in per_rank], "devices": names}
+
+
+def run_stub(args, rank, world):
+    """--stub-model (TEST ONLY): the launcher, the rank environment, the barrier-bracketed step loop, the pose all-gather, the
+    max-over-ranks clock and rank 0's JSON line on CPU tensors over gloo, with a few matrix products standing in for the forward.
+    `"data": "stub"` marks the line: it measures nothing."""
+    dist = None
+    dev = torch.device("cpu")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(B, S - 1, 64, generator=g)
+    w = torch.randn(64, 6, generator=g)
+    gathered = torch.empty(world * B, S - 1, 6) if world > 1 else None
+
+    def step():
+        poses = torch.tanh(x @ w)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, poses)
+        return poses
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:   # every rank must hold every rank's poses: rank r's block is tanh(x_r w_r) of ITS generator
+        gr = torch.Generator().manual_seed(100 + (rank + 1) % world)
+        xo, wo = torch.randn(B, S - 1, 64, generator=gr), torch.randn(64, 6, generator=gr)
+        o = (rank + 1) % world
+        assert torch.allclose(gathered[o * B:(o + 1) * B], torch.tanh(xo @ wo)), "all-gather did not deliver the other rank's poses"
+    elapsed, ranks = rank_report(dist, world, elapsed, args.steps, dev)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(world * B * S * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+                          "config": {"workload": "STUB (tests only): no model, no GPU", "sequences_per_gpu": B, "seq_len": S,
+                                     "sharding": f"sequences x{world}"},
+                          "ranks": ranks}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +409,9 @@ def main():
                          "path, where dX/dt moves every feature channel and each evaluation streams the whole last layer")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp32_mfma", "fp16", "bf16"],
                     help="arithmetic of the HIP path (build extension; only fp32 / fp32_mfma carry the 1e-4 parity claim)")
+    ap.add_argument("--stub-model", action="store_true",
+                    help="TEST ONLY (tests/test_bench_launch.py): a stand-in for the model on CPU tensors with the gloo backend, so that the "
+                         "launcher -> ranks -> step loop -> rank-0 line path can be exercised without GPUs; never a measurement")
     ap.add_argument("--ode-solver", default="rk4")
     ap.add_argument("--drop", type=float, default=0.0, help="frame-drop probability of the synthetic timestamps")
     args = ap.parse_args()
@@ -360,6 +432,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if args.stub_model:
+        return run_stub(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dist = None
@@ -410,10 +484,7 @@ def main():
     elapsed = time.perf_counter() - t0
     stage_ms = model.profile_read()   # averages over the K timed steps
     model.check()
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, ranks = rank_report(dist, world, elapsed, args.steps, torch.device("cuda", local_rank))
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -438,6 +509,7 @@ def main():
                            {"intervals_per_s": round((S - 1) / integ_s, 1), "rows": rows, "unit": f"frame intervals/s of the [32,768] state ({args.ode_solver}, adaptive steps), RNN cell included",
                             "ms_per_forward": round(stage_ms["integrator"], 4)}),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "ranks": ranks,
             "roofline": conv_roofline(conv_tflops),
             "roofline_integrator": {"kernel": "integrator_kernel", "bound": "hbm",
                                     "achieved": round(integ_bytes / integ_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

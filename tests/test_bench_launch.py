@@ -49,3 +49,28 @@ def test_world_size_mismatch_is_refused(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code not in (0, None)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_launcher_to_rank0_line_end_to_end_over_gloo(world):
+    """`python bench.py --gpus N --stub-model`: the REAL launcher path (self-started torch.distributed.run children, rank
+    environment, barrier-bracketed step loop, pose all-gather, max-over-ranks clock, rank 0's JSON line) with a stand-in for the
+    model on CPU tensors over gloo.  What a future SCALE record is checked by: `ranks.collective_world` (the sum of ones over a
+    real all-reduce) must equal n_gpus, every rank reports its own time and device, and `ms_per_step` is the slowest rank's."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--stub-model", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == 4 and out["warmup"] == 1 and out["data"] == "stub" and out["scaling"] == "weak"
+    rk = out["ranks"]
+    assert rk["collective_world"] == world and len(rk["per_rank_ms_per_step"]) == world and len(rk["devices"]) == world
+    assert abs(out["ms_per_step"] - max(rk["per_rank_ms_per_step"])) < 1e-3
+    assert abs(out["value"] - world * 16 * 11 / (out["ms_per_step"] * 1e-3)) <= 0.01 * out["value"]
+    if world > 1:
+        assert rk["backend"] == "gloo"
