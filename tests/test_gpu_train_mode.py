@@ -234,7 +234,8 @@ def test_train_epoch_follows_torch_with_batchnorm_in_train_mode(optimizer, accum
             assert float((d > 0.03 * lr).float().mean()) < 3e-3, n
         else:
             moved = float((leaves[n].detach() - sd[n]).abs().max())
-            assert float(d.max()) <= 2e-3 * moved + 1e-9, (n, float(d.max()), moved)
+            ulp = 1.2e-7 * float(leaves[n].detach().abs().max())          # the update is only a few hundred ulp of the parameter itself
+            assert float(d.max()) <= 2e-3 * moved + 2 * ulp, (n, float(d.max()), moved)
     now = model.state_dict()
     for k in now:
         if "running" in k:
