@@ -186,9 +186,20 @@ int odevio_pose_loss(const float* poses, const float* gts, int32_t n_rows, float
  * LeakyReLU(0.1) -> Dropout(0.2; conv6: 0.5), then the visual head.  `stats`: device tensors named like the module's buffers
  * ("Image_net.conv3_1.1.running_mean" / ".running_var", fp32 [Cout]) that are updated IN PLACE as torch does (momentum 0.1, unbiased
  * variance); buffers not listed are left alone (num_batches_tracked is the caller's counter).  Each block's dropout mask is one
- * draw of the plan's random stream (9 draws, conv1 first; odevio_rng_state BEFORE the call gives the first).  fp32 frames only. */
+ * draw of the plan's random stream (9 draws, conv1 first; odevio_rng_state BEFORE the call gives the first).  fp32 frames only.
+ * keep = 1: what odevio_image_encoder_bwd needs stays behind (about 8 bytes per activation element of the nine blocks). */
 int odevio_image_encoder_fwd_train(odevio_plan* plan, const float* img, int32_t B, int32_t S, float* fv, int32_t ld_fv,
-                                   const odevio_tensor* stats, int32_t n_stats, void* stream);
+                                   const odevio_tensor* stats, int32_t n_stats, int32_t keep, void* stream);
+/* Backward of the forward above when it ran with keep = 1 (every block's bare convolution, output and batch statistics stay in
+ * plan-owned memory until the next train-mode forward): gradients of the Image_net parameters named in `grads`
+ * ("Image_net.conv2.0.weight" [Cout,Cin,k,k], "....1.weight" / "....1.bias" = BatchNorm gamma / beta, "Image_net.visual_head.weight" in
+ * the reference's (C,H,W) column order, ".bias") from grad_fv [B*(S-1)][ld_gfv] - what loss.backward() leaves on Image_net when
+ * --freeze_encoder is off, the gradients that then count in clip_grad_norm_ (scripts/train_model.py:78,84).  Through Dropout (the
+ * same Philox masks), LeakyReLU, batch-statistics BatchNorm (torch's batch_norm backward with training = True) and the convolutions
+ * (weight gradients: contraction over every pixel on the fp32 MFMA; input gradients: stride-1 convolutions of the zero-dilated
+ * gradient with the reversed filters).  All fp32; `img` = the frames of that forward. */
+int odevio_image_encoder_bwd(odevio_plan* plan, const float* img, int32_t B, int32_t S, const float* grad_fv, int32_t ld_gfv,
+                             const odevio_tensor* grads, int32_t n_grads, void* stream);
 /* InertialEncoder.forward in train mode: BatchNorm1d over the (pair, time) rows of the batch, Dropout(p_drop = opt.imu_dropout)
  * after every block; three draws of the random stream (consumed whatever p_drop is); `stats` as above
  * ("Inertial_net.encoder_conv.1.running_mean", ...). */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update", "odevio_imu_encoder_bwd", "odevio_set_seed",
     "odevio_rng_state", "odevio_debug_gumbel", "odevio_fuse_hard_bwd", "odevio_set_rng_state",
     "odevio_image_encoder_fwd_train", "odevio_imu_encoder_fwd_train", "odevio_imu_encoder_bwd_train", "odevio_debug_dropout",
-    "odevio_sgd_step",
+    "odevio_sgd_step", "odevio_image_encoder_bwd",
 ]
 
 
@@ -122,7 +122,8 @@ def load():
     u64 = ctypes.c_uint64
     lib.odevio_rng_state.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     lib.odevio_set_rng_state.argtypes = [vp, u64, u64]
-    lib.odevio_image_encoder_fwd_train.argtypes = [vp, fp, i32, i32, fp, i32, ctypes.POINTER(OdevioTensor), i32, vp]
+    lib.odevio_image_encoder_fwd_train.argtypes = [vp, fp, i32, i32, fp, i32, ctypes.POINTER(OdevioTensor), i32, i32, vp]
+    lib.odevio_image_encoder_bwd.argtypes = [vp, fp, i32, i32, fp, i32, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_imu_encoder_fwd_train.argtypes = [vp, fp, i32, i32, f32, ctypes.POINTER(OdevioTensor), i32, fp, i32, vp]
     lib.odevio_imu_encoder_bwd_train.argtypes = [vp, fp, i32, i32, f32, u64, u64, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_debug_dropout.argtypes = [u64, u64, f32, ctypes.c_int64, fp, vp]

@@ -18,6 +18,7 @@
 #include "integrator.h"
 #include "train.h"
 #include "bn_train.h"
+#include "enc_bwd.h"
 
 // roctx ranges at the two sites the reference marks with NVTX (src/models/PoseODERNN.py:103-104 "ODE", :118-119 "RNN"),
 // plus the encoders: visible in rocprofv3 --marker-trace.  libroctx64 is looked up at run time (no link dependency);
@@ -103,6 +104,15 @@ struct odevio_plan {
   float *bn_scale = nullptr, *bn_shift = nullptr;   // [1024] each: the affine pair of the block being normalised
   float *imu_gamma[3] = {}, *imu_beta[3] = {};
   DevBuf bn_partial;
+  // image-encoder backward (enc_bwd.hip): the flipped / transposed filters of the input-gradient convolutions, what a train-mode
+  // forward with keep = 1 leaves behind (per block the bare convolution z and the block's output a, both P2; the batch statistics),
+  // and scratch
+  float* conv_wT[9] = {};                  // [Cin][kh][kw][Cout], taps reversed (blocks 1..8)
+  DevBuf enc_z[9], enc_a[9];
+  float *enc_mean[9] = {}, *enc_invstd[9] = {};
+  int enc_B = 0, enc_S = 0;                // shape of the kept forward (0: none)
+  unsigned long long enc_seed = 0, enc_call0 = 0;
+  DevBuf enc_gA, enc_D, enc_Dd, enc_part, enc_headT;
   int conv_math = 1;       // 1: fp16x2 operand split on the fp16 MFMA (default); 0: fp32-input MFMA (ODEVIO_CONV_MATH=f32)
   DevBuf pack_tmp, ingest, partial_side;
   // the inertial encoder runs beside the image encoder on its own stream (odevio_forward)
@@ -201,7 +211,9 @@ static int ensure(DevBuf& b, size_t n) {
 // Bytes from `ptr` to the end of the plan-owned buffer that contains it (what a kernel may touch), or `fallback` for
 // memory the caller owns (its extent is the caller's contract).
 static size_t extent_of(const odevio_plan* p, const void* ptr, size_t fallback) {
-  const DevBuf* bufs[] = {&p->actA, &p->actB, &p->pack_tmp, &p->partial, &p->partial_side, &p->ingest, &p->fcat, &p->fused, &p->out_seq};
+  const DevBuf* bufs[] = {&p->actA, &p->actB, &p->pack_tmp, &p->partial, &p->partial_side, &p->ingest, &p->fcat, &p->fused, &p->out_seq,
+                          &p->enc_z[0], &p->enc_z[1], &p->enc_z[2], &p->enc_z[3], &p->enc_z[4], &p->enc_z[5], &p->enc_z[6], &p->enc_z[7], &p->enc_z[8],
+                          &p->enc_a[0], &p->enc_a[1], &p->enc_a[2], &p->enc_a[3], &p->enc_a[4], &p->enc_a[5], &p->enc_a[6], &p->enc_a[7], &p->enc_a[8]};
   const uintptr_t a = (uintptr_t)ptr;
   for (const DevBuf* b : bufs) {
     const uintptr_t lo = (uintptr_t)b->p, hi = lo + b->n * sizeof(float);
@@ -345,8 +357,12 @@ extern "C" void odevio_plan_destroy(odevio_plan* p) {
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (void* q : p->owned) (void)hipFree(q);
   for (DevBuf* b : {&p->actA, &p->actB, &p->imu_act, &p->fcat, &p->fused, &p->out_seq, &p->reg_hid, &p->partial,
-                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side, &p->train_ws, &p->train_log, &p->train_aux, &p->bn_partial})
+                    &p->cde_ws, &p->cde_fn_ws, &p->pack_tmp, &p->ingest, &p->partial_side, &p->train_ws, &p->train_log, &p->train_aux, &p->bn_partial,
+                    &p->enc_gA, &p->enc_D, &p->enc_Dd, &p->enc_part, &p->enc_headT})
     if (b->p) (void)hipFree(b->p);
+  for (int i = 0; i < 9; ++i)
+    for (DevBuf* b : {&p->enc_z[i], &p->enc_a[i]})
+      if (b->p) (void)hipFree(b->p);
   delete p;
 }
 
@@ -639,6 +655,17 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
       TRY(wt.get(pre + ".1.bias", cs.cout, bt));
       TRY(upload(p, &p->conv_gamma[i], gm, st));
       TRY(upload(p, &p->conv_beta[i], bt, st));
+      std::vector<float> zc((size_t)cs.cout, 0.f);
+      TRY(upload(p, &p->enc_mean[i], zc, st));
+      TRY(upload(p, &p->enc_invstd[i], zc, st));
+      if (i > 0) {   // input gradient = stride-1 convolution with the filter's taps reversed and its channel roles swapped
+        const int kk = cs.k * cs.k;
+        std::vector<float> wT(w.size());
+        for (int n = 0; n < cs.cout; ++n)
+          for (int c = 0; c < cs.cin; ++c)
+            for (int q = 0; q < kk; ++q) wT[((size_t)c * kk + (kk - 1 - q)) * cs.cout + n] = w[((size_t)n * cs.cin + c) * kk + q];
+        TRY(upload(p, &p->conv_wT[i], wT, st));
+      }
     }
     TRY(upload(p, &p->conv_scale[i], sc, st));
     TRY(upload(p, &p->conv_shift[i], sh, st));
@@ -1164,27 +1191,151 @@ static float* named_ptr(const odevio_tensor* t, int n, const std::string& name, 
 // Dropout(0.2) - conv6: Dropout(0.5) - on, :82-90): per block conv (identity epilogue) -> batch statistics -> normalise +
 // LeakyReLU + dropout in place.  Each block's mask is one draw of the plan's random stream (9 draws per call, conv1 first).
 static int image_encoder_train(odevio_plan* p, const float* img, int B, int S, float* fv, int ld_fv, const odevio_tensor* stats, int n_stats,
-                               hipStream_t st) {
+                               bool keep, hipStream_t st) {
   RoctxRange range("odevio: ImageEncoder (train mode)");
   if (p->conv_math == 0) return fail(ODEVIO_ERR_UNSUPPORTED, "train-mode encoders need the fp16x2 encoder (unset ODEVIO_CONV_MATH=f32 / --dtype fp32_mfma)");
   const int P = B * (S - 1);
   int rc;
   if ((rc = ensure_act(p, P)) || (rc = ensure(p->bn_partial, (size_t)4 * BN_MAX_BLOCKS * 1024))) return rc;   // doubles in a float buffer
+  p->enc_B = p->enc_S = 0;
+  if (keep) {   // every block's bare convolution AND output stay behind for odevio_image_encoder_bwd (allocations before any launch)
+    for (int i = 0; i < 9; ++i) {
+      const size_t n = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * kConvs[i].cout;
+      if ((rc = ensure(p->enc_z[i], n)) || (rc = ensure(p->enc_a[i], n))) return rc;
+    }
+    p->enc_seed = p->seed;
+    p->enc_call0 = p->rng_calls;
+  }
   float* cur = nullptr;
   for (int i = 0; i < 9; ++i) {
     const ConvSpec& cs = kConvs[i];
     float* nxt = (i == 0 || cur == p->actB.p) ? p->actA.p : p->actB.p;
-    if ((rc = conv_block(p, i, i == 0 ? (const void*)img : (const void*)cur, B, S, nxt, i > 0, true, st, false, 2))) return rc;
+    float* zbuf = keep ? p->enc_z[i].p : nxt;
+    float* abuf = keep ? p->enc_a[i].p : nxt;
+    if ((rc = conv_block(p, i, i == 0 ? (const void*)img : (const void*)cur, B, S, zbuf, i > 0, true, st, false, 2))) return rc;
     const size_t M = (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1];
     const std::string bn = std::string("Image_net.") + cs.name + ".1";
-    HIPCHK(bn_stats_p2(nxt, M, cs.cout, reinterpret_cast<double*>(p->bn_partial.p), p->conv_gamma[i], p->conv_beta[i], 1e-5f, 0.1f,
+    HIPCHK(bn_stats_p2(zbuf, M, cs.cout, reinterpret_cast<double*>(p->bn_partial.p), p->conv_gamma[i], p->conv_beta[i], 1e-5f, 0.1f,
                        named_ptr(stats, n_stats, bn + ".running_mean", cs.cout), named_ptr(stats, n_stats, bn + ".running_var", cs.cout),
-                       p->bn_scale, p->bn_shift, st));
+                       p->bn_scale, p->bn_shift, keep ? p->enc_mean[i] : nullptr, keep ? p->enc_invstd[i] : nullptr, st));
     const DropoutSpec d = make_dropout(p->seed, p->rng_calls++, i == 8 ? 0.5f : 0.2f);
-    HIPCHK(bn_apply_p2(nxt, M, cs.cout, p->bn_scale, p->bn_shift, 0.1f, d, p->status, st));
-    cur = nxt;
+    HIPCHK(bn_apply_p2(zbuf, abuf, M, cs.cout, p->bn_scale, p->bn_shift, 0.1f, d, p->status, st));
+    cur = abuf;
   }
-  return visual_head(p, cur, P, fv, ld_fv, p->head_scale_raw, st);
+  rc = visual_head(p, cur, P, fv, ld_fv, p->head_scale_raw, st);
+  if (!rc && keep) { p->enc_B = B; p->enc_S = S; }
+  return rc;
+}
+
+// Backward of image_encoder_train (the forward that ran last with keep = 1, same B and S): gradients of every Image_net parameter
+// that is asked for, block by block from the head down (enc_bwd.h).  The input gradient of block i is a stride-1 convolution of the
+// (zero-dilated, for the stride-2 blocks) gradient D of its bare convolution with the tap-reversed filter, on conv_igemm_kernel.
+static int image_encoder_bwd(odevio_plan* p, const float* img, int B, int S, const float* g_fv, int ld_gfv, const odevio_tensor* grads, int n_grads,
+                             hipStream_t st) {
+  RoctxRange range("odevio: ImageEncoder backward");
+  if (p->enc_B != B || p->enc_S != S)
+    return fail(ODEVIO_ERR_BAD_ARG, "odevio_image_encoder_bwd: no kept train-mode forward of this shape (odevio_image_encoder_fwd_train with keep = 1 first)");
+  const int P = B * (S - 1), V = p->cfg.v_f_len;
+  auto grad_ptr = [&](const std::string& name, int64_t numel) { return named_ptr(grads, n_grads, name, numel); };
+  for (int i = 0; i < n_grads; ++i) {
+    if (!grads[i].name || !grads[i].data) return fail(ODEVIO_ERR_BAD_ARG, "odevio_image_encoder_bwd: gradient %d has no name / pointer", i);
+    const std::string nm = grads[i].name;
+    int64_t want = -1;
+    for (int l = 0; l < 9 && want < 0; ++l) {
+      const std::string pre = std::string("Image_net.") + kConvs[l].name;
+      if (nm == pre + ".0.weight") want = (int64_t)kConvs[l].cout * kConvs[l].cin * kConvs[l].k * kConvs[l].k;
+      else if (nm == pre + ".1.weight" || nm == pre + ".1.bias") want = kConvs[l].cout;
+    }
+    if (nm == "Image_net.visual_head.weight") want = (int64_t)V * p->head_k;
+    if (nm == "Image_net.visual_head.bias") want = V;
+    if (want < 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_image_encoder_bwd: '%s' is not a parameter of Image_net", nm.c_str());
+    if (want != grads[i].numel) return fail(ODEVIO_ERR_BAD_ARG, "odevio_image_encoder_bwd: gradient '%s' has the wrong size", nm.c_str());
+  }
+  // ---- workspace, sized before any launch
+  size_t n_act = 0, n_dil = 0, n_part = 1;
+  for (int i = 0; i < 9; ++i) {
+    const ConvSpec& cs = kConvs[i];
+    n_act = std::max(n_act, (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * cs.cout);
+    if (i > 0 && cs.stride > 1) n_dil = std::max(n_dil, (size_t)P * p->conv_h[i] * p->conv_w_sp[i] * cs.cout);
+    const int cin_k = i == 0 ? 8 : cs.cin;
+    const int M = P * p->conv_h[i + 1] * p->conv_w_sp[i + 1];
+    n_part = std::max(n_part, enc_wgrad_partial_floats(cs.cout, cin_k, cs.k * cs.k, enc_wgrad_pick_splits(M, cs.cout, cin_k, cs.k * cs.k)));
+  }
+  n_act = std::max(n_act, (size_t)P * p->conv_h[0] * p->conv_w_sp[0] * 8);   // conv1's frame pairs as NHWC with 8 slots
+  n_act = std::max(n_act, (size_t)V * p->head_k);                             // the head's weight gradient before its permutation
+  int rc;
+  if ((rc = ensure(p->enc_gA, n_act)) || (rc = ensure(p->enc_D, n_act)) || (rc = ensure(p->enc_Dd, std::max<size_t>(n_dil, 4))) ||
+      (rc = ensure(p->enc_part, n_part + 4096)) || (rc = ensure(p->enc_headT, (size_t)V * p->head_k)) ||
+      (rc = ensure(p->bn_partial, (size_t)4 * BN_MAX_BLOCKS * 1024)))
+    return rc;
+  float *gA = p->enc_gA.p, *D = p->enc_D.p;
+  float* sums = p->enc_part.p + n_part;   // [2][<= 1024]
+  // ---- visual head: fv = flat(a8) W^T + b with the plan's (H, W, C) column order
+  {
+    const int oh = p->conv_h[9], ow = p->conv_w_sp[9];
+    launch_pair_unpack(p->enc_a[8].p, D, (size_t)P * oh * ow, 1024, st);                       // a8 as fp32 [P][head_k]
+    if (float* gw = grad_ptr("Image_net.visual_head.weight", (int64_t)V * p->head_k)) {
+      skinny_tn(g_fv, ld_gfv, D, p->head_k, gA, p->head_k, P, V, p->head_k, st);                  // [V][(H,W,C)]
+      enc_head_grad_permute(gA, gw, V, 1024, oh * ow, st);                                       // -> the reference's (C,H,W) flatten order
+    }
+    if (float* gb = grad_ptr("Image_net.visual_head.bias", V)) {
+      if (ld_gfv != V) return fail(ODEVIO_ERR_BAD_ARG, "odevio_image_encoder_bwd: the head's bias gradient needs contiguous grad_fv rows");
+      colsum_rows(g_fv, gb, P, V, st);
+    }
+    relayout_transpose(p->head_w, p->enc_headT.p, V, p->head_k, st);                             // [V][head_k] -> [head_k][V]
+    skinny_linear(g_fv, ld_gfv, p->enc_headT.p, V, nullptr, gA, p->head_k, P, p->head_k, V, st); // g_a8 [P][head_k] = g_fv W
+  }
+  for (int i = 8; i >= 0; --i) {
+    const ConvSpec& cs = kConvs[i];
+    const int Ho = p->conv_h[i + 1], Wo = p->conv_w_sp[i + 1], Hi = p->conv_h[i], Wi = p->conv_w_sp[i];
+    const size_t M = (size_t)P * Ho * Wo;
+    const int pad = (cs.k - 1) / 2;
+    const std::string pre = std::string("Image_net.") + cs.name;
+    const DropoutSpec d = make_dropout(p->enc_seed, p->enc_call0 + i, i == 8 ? 0.5f : 0.2f);
+    HIPCHK(enc_bn_bwd_reduce(gA, p->enc_z[i].p, M, cs.cout, p->enc_mean[i], p->enc_invstd[i], p->conv_gamma[i], p->conv_beta[i], d,
+                             reinterpret_cast<double*>(p->bn_partial.p), sums, st));
+    if (float* gb = grad_ptr(pre + ".1.bias", cs.cout)) HIPCHK(hipMemcpyAsync(gb, sums, cs.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (float* gg = grad_ptr(pre + ".1.weight", cs.cout)) HIPCHK(hipMemcpyAsync(gg, sums + cs.cout, cs.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(enc_bn_bwd_apply(gA, p->enc_z[i].p, M, cs.cout, p->enc_mean[i], p->enc_invstd[i], p->conv_gamma[i], p->conv_beta[i], d, sums, D, st));
+    // ---- weight gradient
+    if (float* gw = grad_ptr(pre + ".0.weight", (int64_t)cs.cout * cs.cin * cs.k * cs.k)) {
+      WgradArgs a{};
+      a.D = D; a.partial = p->enc_part.p; a.dW = gw;
+      a.N = P; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.Cout = cs.cout; a.KH = a.KW = cs.k; a.stride = cs.stride; a.pad = pad; a.M = (int)M;
+      if (i == 0) {
+        enc_pairs_nhwc8(img, gA, B, S, Hi, Wi, st);   // (gA is free: D holds this block's gradient, and block 0 has no input gradient)
+        a.x = gA; a.x_f32 = 1; a.ldx = 8; a.Cin = 8; a.cin_out = 6;
+      } else {
+        a.x = p->enc_a[i - 1].p; a.x_f32 = 0; a.Cin = cs.cin; a.cin_out = cs.cin;
+      }
+      a.splits = enc_wgrad_pick_splits(a.M, a.Cout, a.Cin, cs.k * cs.k);
+      HIPCHK(enc_wgrad(a, st));
+    }
+    if (i == 0) break;
+    // ---- input gradient -> gA [P * Hi * Wi][Cin]
+    const float* din = D;
+    int Hd = Ho, Wd = Wo;
+    if (cs.stride > 1) {
+      Hd = Hi + 2 * pad - cs.k + 1;
+      Wd = Wi + 2 * pad - cs.k + 1;
+      enc_dilate(D, p->enc_Dd.p, P, Ho, Wo, Hd, Wd, cs.cout, cs.stride, st);
+      din = p->enc_Dd.p;
+    }
+    ConvArgs c{};
+    c.in = din; c.w = p->conv_wT[i]; c.out = gA;
+    c.N = P; c.Hi = Hd; c.Wi = Wd; c.Cin = cs.cout; c.Ho = Hi; c.Wo = Wi; c.Cout = cs.cin; c.KH = c.KW = cs.k; c.stride = 1; c.pad = cs.k - 1 - pad;
+    c.M = P * Hi * Wi; c.ld_out = cs.cin; c.act = EPI_NONE; c.slope = 0.f;
+    const int nk = cs.k * cs.k * cs.cout / 32;
+    c.splitk = pick_splitk(c.M, c.Cout, nk);
+    c.ktiles_per_split = (nk + c.splitk - 1) / c.splitk;
+    c.splitk = (nk + c.ktiles_per_split - 1) / c.ktiles_per_split;
+    if (c.splitk > 1) {
+      if ((rc = ensure(p->partial, (size_t)c.splitk * c.M * c.Cout))) return rc;
+      c.partial = p->partial.p;
+    }
+    launch_conv_igemm(c, st);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : fail(ODEVIO_ERR_HIP, "odevio_image_encoder_bwd: a kernel failed to launch");
 }
 
 static int imu_encoder(odevio_plan* p, const float* imu, int B, int T, float* fi, int ld_fi, hipStream_t st,
@@ -2039,13 +2190,21 @@ static void fill_imu_train_mode(odevio_plan* p, ImuTrainMode& tm, float p_drop, 
 }
 
 extern "C" int odevio_image_encoder_fwd_train(odevio_plan* p, const float* img, int32_t B, int32_t S, float* fv, int32_t ld_fv,
-                                              const odevio_tensor* stats, int32_t n_stats, void* stream) {
+                                              const odevio_tensor* stats, int32_t n_stats, int32_t keep, void* stream) {
   ARGCHK(p && img && fv && B > 0 && S > 1 && ld_fv >= p->cfg.v_f_len && n_stats >= 0 && (stats || n_stats == 0),
          "odevio_image_encoder_fwd_train: bad argument");
   POLL(p, stream);
-  const int rc = image_encoder_train(p, img, B, S, fv, ld_fv, stats, n_stats, (hipStream_t)stream);
+  const int rc = image_encoder_train(p, img, B, S, fv, ld_fv, stats, n_stats, keep != 0, (hipStream_t)stream);
   post_status(p, (hipStream_t)stream);
   return rc;
+}
+
+extern "C" int odevio_image_encoder_bwd(odevio_plan* p, const float* img, int32_t B, int32_t S, const float* grad_fv, int32_t ld_gfv,
+                                        const odevio_tensor* grads, int32_t n_grads, void* stream) {
+  ARGCHK(p && img && grad_fv && B > 0 && S > 1 && ld_gfv >= p->cfg.v_f_len && n_grads >= 0 && (grads || n_grads == 0),
+         "odevio_image_encoder_bwd: bad argument");
+  POLL(p, stream);
+  return image_encoder_bwd(p, img, B, S, grad_fv, ld_gfv, grads, n_grads, (hipStream_t)stream);
 }
 
 extern "C" int odevio_imu_encoder_fwd_train(odevio_plan* p, const float* imu, int32_t B, int32_t T, float p_drop, const odevio_tensor* stats,

@@ -13,13 +13,13 @@
 // pieces) -> scale / shift of y = z * scale + shift = gamma (z - mean) / sqrt(var + eps) + beta (biased variance, like
 // torch.nn.functional.batch_norm(training=True)), and the running statistics updated in place the way torch does:
 //   running_mean = momentum * mean + (1 - momentum) * running_mean;  running_var likewise with the UNBIASED variance.
-// partial: 2 * BN_MAX_BLOCKS * C doubles of scratch.  run_mean / run_var may be null (no update).
-// Sums run in double in a fixed order (deterministic).
+// partial: 2 * BN_MAX_BLOCKS * C doubles of scratch.  run_mean / run_var may be null (no update); mean_out / invstd_out (both or
+// neither): the batch statistics themselves, kept for the backward.  Sums run in double in a fixed order (deterministic).
 hipError_t bn_stats_p2(const void* z, size_t M, int C, double* partial, const float* gamma, const float* beta, float eps, float momentum,
-                       float* run_mean, float* run_var, float* scale, float* shift, hipStream_t st);
-// In place: z <- split(leaky(z * scale[c] + shift[c], slope) * dropout), element index of the mask = pixel * C + channel (NHWC).
-hipError_t bn_apply_p2(void* z, size_t M, int C, const float* scale, const float* shift, float slope, const DropoutSpec& drop, int* status,
-                       hipStream_t st);
+                       float* run_mean, float* run_var, float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t st);
+// out <- split(leaky(z * scale[c] + shift[c], slope) * dropout) (out may be z: in place), element index of the mask = pixel * C + channel (NHWC).
+hipError_t bn_apply_p2(const void* z, void* out, size_t M, int C, const float* scale, const float* shift, float slope, const DropoutSpec& drop,
+                       int* status, hipStream_t st);
 // The same statistics for a row matrix x [rows][C] fp32 (the inertial encoder's (pair, time step) rows): mean / invstd out,
 // running statistics updated as above.  One workgroup per channel.
 hipError_t bn_stats_rows(const float* x, size_t rows, int C, float eps, float momentum, float* run_mean, float* run_var, float* mean,

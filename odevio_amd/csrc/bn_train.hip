@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void bn_stats_p2_kernel(const unsigned char* _
 // one thread per channel: block partials in block order -> statistics -> affine pair; running statistics like torch
 __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift) {
+                                   float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0, q = 0.0;
@@ -68,6 +69,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nblk,
   const float sc = gamma[c] * invstd;
   scale[c] = sc;
   shift[c] = beta[c] - (float)mean * sc;
+  if (mean_out) { mean_out[c] = (float)mean; invstd_out[c] = invstd; }   // kept for the backward
   if (run_mean) run_mean[c] = momentum * (float)mean + (1.0f - momentum) * run_mean[c];
   if (run_var) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -75,7 +77,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nblk,
   }
 }
 
-__global__ __launch_bounds__(256) void bn_apply_p2_kernel(unsigned char* __restrict__ z, size_t M, int C, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void bn_apply_p2_kernel(const unsigned char* z, unsigned char* out, size_t M, int C, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float slope, DropoutSpec drop, int* status) {
   const int Q = C >> 2;
   const size_t total = M * (size_t)Q;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(256) void bn_apply_p2_kernel(unsigned char* __restr
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t m = i / Q;
     const int c = 4 * (int)(i - m * Q);
-    unsigned char* p = z + (m * gpp + (size_t)(c >> 5)) * 128 + (size_t)(c & 31) * 2;
+    const size_t off = (m * gpp + (size_t)(c >> 5)) * 128 + (size_t)(c & 31) * 2;
+    const unsigned char* p = z + off;
     const f16x4_t h = *reinterpret_cast<const f16x4_t*>(p), l = *reinterpret_cast<const f16x4_t*>(p + 64);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
     unsigned bits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -99,8 +102,8 @@ __global__ __launch_bounds__(256) void bn_apply_p2_kernel(unsigned char* __restr
       ho[e] = (_Float16)x;
       lo[e] = (_Float16)(x - (float)ho[e]);
     }
-    *reinterpret_cast<f16x4_t*>(p) = ho;
-    *reinterpret_cast<f16x4_t*>(p + 64) = lo;
+    *reinterpret_cast<f16x4_t*>(out + off) = ho;
+    *reinterpret_cast<f16x4_t*>(out + off + 64) = lo;
   }
   if (bad) status[ODEVIO_STATUS_RANGE] = 1;
 }
@@ -144,24 +147,25 @@ __global__ void dropout_dump_kernel(float* __restrict__ out, size_t n, DropoutSp
 }
 
 hipError_t bn_stats_p2(const void* z, size_t M, int C, double* partial, const float* gamma, const float* beta, float eps, float momentum,
-                       float* run_mean, float* run_var, float* scale, float* shift, hipStream_t st) {
+                       float* run_mean, float* run_var, float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t st) {
   if (!z || !partial || !gamma || !beta || !scale || !shift || M == 0 || C < 64 || C > 1024 || (C & (C - 1))) return hipErrorInvalidValue;
   const int PL = 256 / (C >> 2);
   const int nblk = (int)std::min<size_t>(BN_MAX_BLOCKS, (M + PL - 1) / PL);
   (void)hipGetLastError();
   hipLaunchKernelGGL(bn_stats_p2_kernel, dim3(nblk), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(z), M, C, partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblk, C, (double)M, gamma, beta, eps, momentum, run_mean,
-                     run_var, scale, shift);
+                     run_var, scale, shift, mean_out, invstd_out);
   return hipGetLastError();
 }
 
-hipError_t bn_apply_p2(void* z, size_t M, int C, const float* scale, const float* shift, float slope, const DropoutSpec& drop, int* status,
-                       hipStream_t st) {
-  if (!z || !scale || !shift || !status || M == 0 || C % 32) return hipErrorInvalidValue;
+hipError_t bn_apply_p2(const void* z, void* out, size_t M, int C, const float* scale, const float* shift, float slope, const DropoutSpec& drop,
+                       int* status, hipStream_t st) {
+  if (!z || !out || !scale || !shift || !status || M == 0 || C % 32) return hipErrorInvalidValue;
   const size_t total = M * (size_t)(C >> 2);
   const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(bn_apply_p2_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<unsigned char*>(z), M, C, scale, shift, slope, drop, status);
+  hipLaunchKernelGGL(bn_apply_p2_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(z),
+                     reinterpret_cast<unsigned char*>(out), M, C, scale, shift, slope, drop, status);
   return hipGetLastError();
 }
 

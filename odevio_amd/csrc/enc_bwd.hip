@@ -1,0 +1,314 @@
+// Backward of the image encoder's conv blocks under model.train(), gfx950 (see enc_bwd.h for what each entry computes and the
+// reference lines it stands for).  Everything here is fp32: gradients span many orders of magnitude, which the two-fp16-piece
+// layout of the forward activations cannot carry without per-tensor exponents; the fp32-input MFMA (v_mfma_f32_16x16x4_f32, an
+// exact fmaf chain) does the contractions.
+#include <algorithm>
+
+#include "common.h"
+#include "enc_bwd.h"
+
+typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// value (m, c .. c+3) of a P2 tensor as fp32
+__device__ __forceinline__ f32x4 p2_load4(const unsigned char* z, size_t m, int c, int C) {
+  const unsigned char* p = z + (m * (size_t)(C >> 5) + (size_t)(c >> 5)) * 128 + (size_t)(c & 31) * 2;
+  const h16x4_t h = *reinterpret_cast<const h16x4_t*>(p), l = *reinterpret_cast<const h16x4_t*>(p + 64);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (float)h[e] + (float)l[e];
+  return v;
+}
+
+// dz and xhat of four consecutive channels of pixel m; i = m * (C / 4) + c / 4 is also the dropout block index
+__device__ __forceinline__ void bn_bwd_point(const float* __restrict__ g_a, const unsigned char* __restrict__ z, size_t i, int Q, int C,
+                                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, const DropoutSpec& drop, f32x4& dz, f32x4& xh, int& c_out) {
+  const size_t m = i / Q;
+  const int c = 4 * (int)(i - m * Q);
+  c_out = c;
+  const f32x4 zv = p2_load4(z, m, c, C);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(g_a + m * (size_t)C + c);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+  unsigned bits[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  if (drop.thr) dropout_bits4(drop, i, bits);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    xh[e] = (zv[e] - mu[e]) * is[e];
+    const float y = fmaf(ga[e], xh[e], be[e]);
+    float f = y > 0.f ? 1.0f : 0.1f;
+    if (drop.thr) f = bits[e] >= drop.thr ? f * drop.scale : 0.f;
+    dz[e] = g[e] * f;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g_a, const unsigned char* __restrict__ z, size_t M, int C,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, DropoutSpec drop,
+                                                            double* __restrict__ partial) {
+  __shared__ double red[256][8];
+  const int tid = threadIdx.x;
+  const int Q = C >> 2, PL = 256 / Q;
+  const int cq = tid % Q, pl = tid / Q;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+  for (size_t m = (size_t)blockIdx.x * PL + pl; m < M; m += (size_t)gridDim.x * PL) {
+    f32x4 dz, xh;
+    int c;
+    bn_bwd_point(g_a, z, m * Q + cq, Q, C, mean, invstd, gamma, beta, drop, dz, xh, c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s[e] += (double)dz[e];
+      q[e] += (double)dz[e] * (double)xh[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[tid][e] = s[e]; red[tid][4 + e] = q[e]; }
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double ss = 0.0, qq = 0.0;
+      for (int j = 0; j < PL; ++j) { ss += red[j * Q + cq][e]; qq += red[j * Q + cq][4 + e]; }
+      double* o = partial + ((size_t)blockIdx.x * C + 4 * cq + e) * 2;
+      o[0] = ss;
+      o[1] = qq;
+    }
+  }
+}
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += partial[((size_t)b * C + c) * 2];
+    q += partial[((size_t)b * C + c) * 2 + 1];
+  }
+  sums[c] = (float)s;
+  sums[C + c] = (float)q;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g_a, const unsigned char* __restrict__ z, size_t M, int C,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, DropoutSpec drop,
+                                                           const float* __restrict__ sums, float* __restrict__ D) {
+  const int Q = C >> 2;
+  const size_t total = M * (size_t)Q;
+  const float invm = 1.0f / (float)M;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 dz, xh, d;
+    int c;
+    bn_bwd_point(g_a, z, i, Q, C, mean, invstd, gamma, beta, drop, dz, xh, c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = gamma[c + e] * invstd[c + e] * (dz[e] - sums[c + e] * invm - xh[e] * sums[C + c + e] * invm);
+    *reinterpret_cast<f32x4*>(D + (i / Q) * (size_t)C + c) = d;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  One workgroup = one 64 (co) x 64 (ci) tile of one filter tap over one range of pixels; 4 waves as 2 x 2, each
+// 32 x 32 = 2 x 2 MFMA tiles.  Both operands arrive PIXEL-major (D [pixel][co], x [pixel][ci]), which is what the 16x16x4 fp32
+// MFMA wants when the contraction runs over pixels: lane (r, q) supplies A[row r][k q] = D[pixel q][co r] and B[k q][col r] =
+// x[pixel q][ci r] - no transpose anywhere.  64-pixel chunks are staged in LDS (row stride 80 floats: the two 32-lane halves of a
+// ds_read_b32 then touch 32 different banks).
+// ---------------------------------------------------------------------------------------------------------------------
+#define WG_PX 64
+#define WG_LD 80
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  __shared__ float Dt[WG_PX * WG_LD], Xt[WG_PX * WG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int taps = a.KH * a.KW;
+  const int tap = blockIdx.x % taps, split = blockIdx.x / taps;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lrow = tid >> 4, lcol = 4 * (tid & 15);     // loader: rows lrow + 16 j, four consecutive channels at lcol
+  const int HoWo = a.Ho * a.Wo;
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+  const float* xf = reinterpret_cast<const float*>(a.x);
+  const int G = a.Cin >> 5;
+  const int chunk_end = min((split + 1) * a.chunks_per_split, (a.M + WG_PX - 1) / WG_PX);
+  for (int ch = split * a.chunks_per_split; ch < chunk_end; ++ch) {
+    const int m0 = ch * WG_PX;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = lrow + 16 * j;
+      const int m = m0 + row;
+      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M) {
+        const int co = co0 + lcol;
+        if (co < a.Cout) dv = *reinterpret_cast<const f32x4*>(a.D + (size_t)m * a.Cout + co);   // (Cout % 4 == 0)
+        const int n = m / HoWo;
+        const int rem = m - n * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        const int hi = ho * a.stride + kh - a.pad, wi = wo * a.stride + kw - a.pad;
+        const int ci = ci0 + lcol;
+        if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi && ci < a.Cin) {
+          const size_t pi = ((size_t)n * a.Hi + hi) * a.Wi + wi;
+          if (a.x_f32) {
+            xv = *reinterpret_cast<const f32x4*>(xf + pi * a.ldx + ci);
+          } else {
+            const unsigned char* p = xb + (pi * (size_t)G + (size_t)(ci >> 5)) * 128 + (size_t)(ci & 31) * 2;
+            const h16x4_t h = *reinterpret_cast<const h16x4_t*>(p), l = *reinterpret_cast<const h16x4_t*>(p + 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = (float)h[e] + (float)l[e];
+          }
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Dt[row * WG_LD + lcol]) = dv;
+      *reinterpret_cast<f32x4*>(&Xt[row * WG_LD + lcol]) = xv;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < WG_PX / 4; ++kk) {
+      const int prow = (4 * kk + q) * WG_LD;
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = Dt[prow + wr * 32 + 16 * i + r];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = Xt[prow + wc * 32 + 16 * j + r];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D map of the 16x16x4 MFMA: lane (r, q), register e = [row 4 q + e][column r] = [co][ci]
+  float* slab = a.partial + ((size_t)split * taps + tap) * a.Cout * a.Cin;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + wr * 32 + 16 * i + 4 * q + e, ci = ci0 + wc * 32 + 16 * j + r;
+        if (co < a.Cout && ci < a.Cin) slab[(size_t)co * a.Cin + ci] = acc[i][j][e];
+      }
+}
+// slabs in slab order -> dW [Cout][Cin][KH][KW]
+__global__ void wgrad_reduce_kernel(WgradArgs a) {
+  const int taps = a.KH * a.KW;
+  const size_t per = (size_t)a.Cout * a.Cin;
+  const size_t total = per * taps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const size_t cc = i / taps;                         // co * Cin + ci
+    const int ci = (int)(cc % a.Cin);
+    if (ci >= a.cin_out) continue;                      // (conv1: 6 real channels in 8 slots)
+    float s = 0.f;
+    for (int z = 0; z < a.splits; ++z) s += a.partial[((size_t)z * taps + tap) * per + cc];
+    a.dW[((cc / a.Cin) * a.cin_out + ci) * taps + tap] = s;
+  }
+}
+
+__global__ void dilate_kernel(const float* __restrict__ D, float* __restrict__ Dd, int N, int Ho, int Wo, int Hd, int Wd, int C, int stride) {
+  const size_t total4 = (size_t)N * Hd * Wd * (C >> 2);
+  const int Q = C >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = 4 * (int)(i % Q);
+    size_t p = i / Q;
+    const int wd = (int)(p % Wd);
+    p /= Wd;
+    const int hd = (int)(p % Hd);
+    const int n = (int)(p / Hd);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (hd % stride == 0 && wd % stride == 0 && hd / stride < Ho && wd / stride < Wo)
+      v = *reinterpret_cast<const f32x4*>(D + (((size_t)n * Ho + hd / stride) * Wo + wd / stride) * C + c);
+    *reinterpret_cast<f32x4*>(Dd + i * 4) = v;
+  }
+}
+__global__ void pairs_nhwc8_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int S, int H, int W) {
+  const size_t HW = (size_t)H * W;
+  const size_t total = (size_t)B * (S - 1) * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pair = i / HW, px = i - pair * HW;
+    const int b = (int)(pair / (S - 1)), s = (int)(pair - (size_t)b * (S - 1));
+    const float* f0 = img + ((size_t)b * S + s) * 3 * HW + px;   // frames s and s + 1: six consecutive planes (Encoder.py:101)
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = f0[(size_t)c * HW];
+    v[6] = v[7] = 0.f;
+    float* o = out + i * 8;
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+}
+__global__ void head_grad_permute_kernel(const float* __restrict__ in, float* __restrict__ out, int n_out, int C, int HW) {
+  const size_t total = (size_t)n_out * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int s = (int)(i % HW);
+    const size_t t = i / HW;
+    const int c = (int)(t % C);
+    const size_t n = t / C;
+    out[i] = in[(n * HW + s) * C + c];
+  }
+}
+
+inline unsigned ew_blocks(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 16384); }
+
+}  // namespace
+
+hipError_t enc_bn_bwd_reduce(const float* g_a, const void* z, size_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, const DropoutSpec& drop, double* partial, float* sums, hipStream_t st) {
+  if (!g_a || !z || !mean || !invstd || !gamma || !beta || !partial || !sums || M == 0 || C < 64 || C > 1024 || (C & (C - 1))) return hipErrorInvalidValue;
+  const int PL = 256 / (C >> 2);
+  const int nblk = (int)std::min<size_t>(1024, (M + PL - 1) / PL);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, g_a, reinterpret_cast<const unsigned char*>(z), M, C, mean, invstd, gamma,
+                     beta, drop, partial);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblk, C, sums);
+  return hipGetLastError();
+}
+
+hipError_t enc_bn_bwd_apply(const float* g_a, const void* z, size_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const DropoutSpec& drop, const float* sums, float* D, hipStream_t st) {
+  if (!g_a || !z || !sums || !D || M == 0 || C % 32) return hipErrorInvalidValue;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * (size_t)(C >> 2))), dim3(256), 0, st, g_a, reinterpret_cast<const unsigned char*>(z), M, C,
+                     mean, invstd, gamma, beta, drop, sums, D);
+  return hipGetLastError();
+}
+
+size_t enc_wgrad_partial_floats(int Cout, int Cin, int taps, int splits) { return (size_t)splits * taps * Cout * Cin; }
+
+int enc_wgrad_pick_splits(int M, int Cout, int Cin, int taps) {
+  const long tiles = (long)taps * ((Cout + 63) / 64) * ((Cin + 63) / 64);
+  const int chunks = (M + WG_PX - 1) / WG_PX;
+  long s = (2048 + tiles - 1) / tiles;            // ~8 workgroups per CU in flight over the launch
+  s = std::max(1L, std::min<long>(s, chunks));
+  s = std::min<long>(s, 256);
+  return (int)s;
+}
+
+hipError_t enc_wgrad(const WgradArgs& a_in, hipStream_t st) {
+  WgradArgs a = a_in;
+  if (!a.D || !a.x || !a.partial || !a.dW || a.M <= 0 || a.Cout % 4 || a.Cin % 4 || a.splits < 1 || (!a.x_f32 && a.Cin % 32) ||
+      (size_t)a.N * a.Ho * a.Wo != (size_t)a.M)
+    return hipErrorInvalidValue;
+  const int chunks = (a.M + WG_PX - 1) / WG_PX;
+  if (a.cin_out <= 0 || a.cin_out > a.Cin) a.cin_out = a.Cin;
+  a.chunks_per_split = (chunks + a.splits - 1) / a.splits;
+  a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+  const int taps = a.KH * a.KW;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(wgrad_kernel, dim3(taps * a.splits, (a.Cout + 63) / 64, (a.Cin + 63) / 64), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_blocks((size_t)a.Cout * a.Cin * taps)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+void enc_dilate(const float* D, float* Dd, int N, int Ho, int Wo, int Hd, int Wd, int C, int stride, hipStream_t st) {
+  hipLaunchKernelGGL(dilate_kernel, dim3(ew_blocks((size_t)N * Hd * Wd * (C >> 2))), dim3(256), 0, st, D, Dd, N, Ho, Wo, Hd, Wd, C, stride);
+}
+void enc_pairs_nhwc8(const float* img, float* out, int B, int S, int H, int W, hipStream_t st) {
+  hipLaunchKernelGGL(pairs_nhwc8_kernel, dim3(ew_blocks((size_t)B * (S - 1) * H * W)), dim3(256), 0, st, img, out, B, S, H, W);
+}
+void enc_head_grad_permute(const float* in, float* out, int n_out, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(head_grad_permute_kernel, dim3(ew_blocks((size_t)n_out * C * HW)), dim3(256), 0, st, in, out, n_out, C, HW);
+}

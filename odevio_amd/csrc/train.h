@@ -92,6 +92,9 @@ int train_imu_bwd_train(const ImuTrain& m, const ImuTrainMode& tm, float* ws, co
 int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, const float* g_fi, float* g_imu_rows, const ImuGrads& g,
                   hipStream_t st);
 void skinny_linear(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, hipStream_t st);
+// out [N][K] (ldo) = sum over M rows of D[m][n] * A[m][k] (weight gradients: contraction over rows); out [N] = column sums of x [M][N]
+void skinny_tn(const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K, hipStream_t st);
+void colsum_rows(const float* x, float* out, int M, int N, hipStream_t st);
 void leaky_inplace(float* x, size_t n, float slope, hipStream_t st);
 void mul_inplace(float* x, const float* y, size_t n, hipStream_t st);   // x *= y
 int train_fuse_hard_bwd(const float* W, const float* W_t, const float* bias, float* cat, float* logits, float* g_logits, float* g_cat,

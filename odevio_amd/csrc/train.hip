@@ -1011,6 +1011,10 @@ int train_imu_bwd_train(const ImuTrain& m, const ImuTrainMode& tm, float* ws, co
 void skinny_linear(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, hipStream_t st) {
   gemm_nt(st, A, lda, W, ldw, bias, out, ldo, M, N, K);
 }
+void skinny_tn(const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K, hipStream_t st) {
+  gemm_tn(st, D, ldd, A, lda, out, ldo, M, N, K);
+}
+void colsum_rows(const float* x, float* out, int M, int N, hipStream_t st) { launch_colsum(st, x, out, M, N); }
 void leaky_inplace(float* x, size_t n, float slope, hipStream_t st) { hipLaunchKernelGGL(leaky_kernel, EW_GRID(n), 0, st, x, n, slope); }
 __global__ void mul_kernel(float* x, const float* y, size_t n) { EW_LOOP(i, n) x[i] *= y[i]; }
 void mul_inplace(float* x, const float* y, size_t n, hipStream_t st) { hipLaunchKernelGGL(mul_kernel, EW_GRID(n), 0, st, x, y, n); }

@@ -351,9 +351,10 @@ class DeepVIO(nn.Module):
         self._plan_sig = self._signature()      # the plan's train-mode inputs are these very buffers: nothing to rebuild ...
         self._bn_dirty = True                   # ... until an eval-mode forward needs the running statistics folded again
 
-    def image_encoder(self, img):
+    def image_encoder(self, img, keep=False):
         """ImageEncoder.forward (Encoder.py:97-122).  In ``train()`` mode: BatchNorm with batch statistics, the modules' running
-        statistics updated in place, Dropout(0.2 / 0.5) with masks from the model's random stream (``set_seed`` / ``rng_state``)."""
+        statistics updated in place, Dropout(0.2 / 0.5) with masks from the model's random stream (``set_seed`` / ``rng_state``);
+        ``keep=True`` leaves what ``odevio_image_encoder_bwd`` needs in the plan (``odevio_amd.train.image_encoder`` uses it)."""
         self._ensure_plan()
         img = self._dev(img, "img")
         B, S = img.shape[0], img.shape[1]
@@ -364,7 +365,7 @@ class DeepVIO(nn.Module):
             for i, (n, t) in enumerate(zip(names, tensors)):
                 arr[i].name, arr[i].data, arr[i].numel = n.encode(), t.data_ptr(), t.numel()
             _lib.check(self._lib.odevio_image_encoder_fwd_train(self._plan, img.data_ptr(), B, S, fv.data_ptr(), self.opt.v_f_len, arr,
-                                                                len(names), self._stream()))
+                                                                len(names), 1 if keep else 0, self._stream()))
             self._after_train_forward(counters)
             return fv
         _lib.check(self._lib.odevio_image_encoder_fwd(self._plan, img.data_ptr(), B, S, fv.data_ptr(), self.opt.v_f_len,

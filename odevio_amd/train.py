@@ -17,10 +17,11 @@ the forward kernels.
 Train-mode semantics.  The reference trains under ``model.train()`` (scripts/train_model.py:219): BatchNorm with batch statistics
 and Dropout in BOTH encoders, the frozen ``Image_net`` included.  With ``model.train()`` set, ``model.image_encoder`` /
 ``imu_encoder`` compute exactly that (``odevio_image_encoder_fwd_train`` / ``odevio_imu_encoder_fwd_train``: running statistics
-moved in place, masks from the model's Philox stream) and ``imu_encoder`` below back-propagates through the batch-statistics
-BatchNorm and the same masks (``odevio_imu_encoder_bwd_train``).  The IMAGE encoder's backward is not built: the reference's own
-recipe freezes it (``--freeze_encoder``, scripts/run_training.sh:24) and ``PoseNetTrainer`` refuses ``freeze_encoder = False``
-instead of silently leaving ``Image_net``'s gradients out of the clipping norm.
+moved in place, masks from the model's Philox stream) and ``imu_encoder`` / ``image_encoder`` below back-propagate through the
+batch-statistics BatchNorm and the same masks (``odevio_imu_encoder_bwd_train``, ``odevio_image_encoder_bwd``).  The reference's own
+recipe freezes ``Image_net`` (``--freeze_encoder``, scripts/run_training.sh:24); with the flag off its gradients are computed and
+count in ``clip_grad_norm_`` exactly as in the reference, whose optimizer nevertheless never updates the encoders
+(utils/utils.py:116-119).
 """
 import ctypes
 
@@ -166,6 +167,54 @@ class _ImuEncoderFunction(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+def image_param_names():
+    """Parameters of ``Image_net`` (Encoder.py:82-95): nine Conv2d (no bias) + BatchNorm2d pairs and the visual head."""
+    from . import weights
+    names = []
+    for name, _, _, _, _ in weights.IMAGE_CONVS:
+        names += [f"Image_net.{name}.0.weight", f"Image_net.{name}.1.weight", f"Image_net.{name}.1.bias"]
+    return names + ["Image_net.visual_head.weight", "Image_net.visual_head.bias"]
+
+
+class _ImageEncoderFunction(torch.autograd.Function):
+    """img [B,S,3,H,W] (+ the Image_net parameters) -> fv [B,S-1,v_f_len]  (ImageEncoder.forward under ``model.train()``: batch-statistics
+    BatchNorm + Dropout) with the backward to every Image_net parameter (``odevio_image_encoder_bwd``).  The frames get no gradient."""
+
+    @staticmethod
+    def forward(ctx, model, names, img, *params):
+        img = img.detach().contiguous().float()
+        fv = model.image_encoder(img, keep=True)
+        ctx.model, ctx.names = model, names
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.needs = [p.requires_grad for p in params]
+        ctx.save_for_backward(img)
+        return fv
+
+    @staticmethod
+    def backward(ctx, g_fv):
+        model = ctx.model
+        (img,) = ctx.saved_tensors
+        g_fv = g_fv.contiguous().float()
+        grads = [torch.empty(s, device=img.device, dtype=torch.float32) if need else None for s, need in zip(ctx.param_shapes, ctx.needs)]
+        pairs = [(n, g) for n, g in zip(ctx.names, grads) if g is not None]
+        model._ensure_plan()
+        _lib.check(model._lib.odevio_image_encoder_bwd(model._plan, img.data_ptr(), img.shape[0], img.shape[1], g_fv.data_ptr(), g_fv.shape[-1],
+                                                       _tensor_array([n for n, _ in pairs], [g for _, g in pairs]), len(pairs), model._stream()))
+        return (None, None, None, *grads)
+
+
+def image_encoder(model, img):
+    """``model.Image_net`` forward WITH an autograd graph to its parameters - train mode only (the reference never back-propagates
+    through an eval-mode encoder: its loop runs under ``model.train()``, scripts/train_model.py:219)."""
+    if not model.training:
+        raise RuntimeError("odevio_amd.train.image_encoder: the image encoder's backward exists for train mode (model.train()) - the mode the "
+                           "reference trains in; eval-mode features carry no graph (model.image_encoder)")
+    model._ensure_plan()
+    names = image_param_names()
+    params = dict(model.named_parameters())
+    return _ImageEncoderFunction.apply(model, names, img, *[params[n] for n in names])
+
+
 def imu_encoder(model, imu):
     """``model.Inertial_net`` forward WITH an autograd graph to its parameters (the raw IMU samples get no gradient)."""
     model._ensure_plan()
@@ -232,12 +281,12 @@ class PoseNetTrainer:
     def __init__(self, model, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, gradient_clip=None, process_group=None,
                  optimizer=None):
         opt = model.opt
-        # what is not built is refused, not approximated (the reference's recipe sets --freeze_encoder: scripts/run_training.sh:24)
-        if not getattr(opt, "freeze_encoder", False):
-            raise NotImplementedError(
-                "PoseNetTrainer: opt.freeze_encoder is False, but the image encoder's backward is not built - the reference would then "
-                "count Image_net's gradients in clip_grad_norm_ (scripts/train_model.py:84); set freeze_encoder=True (the reference "
-                "recipe's own setting)")
+        # --freeze_encoder (scripts/train_model.py:191-194: requires_grad = False on Image_net; the recipe's setting): Image_net runs
+        # without a graph.  Otherwise its gradients exist and count in clip_grad_norm_(model.parameters()) (:84) although the optimizer
+        # never holds them (utils/utils.py:116-119) - reproduced through odevio_amd.train.image_encoder
+        self.freeze_encoder = bool(getattr(opt, "freeze_encoder", False))
+        for q in model.Image_net.parameters():
+            q.requires_grad_(not self.freeze_encoder)
         self.optimizer = str(getattr(opt, "optimizer", "Adam") if optimizer is None else optimizer)
         if self.optimizer not in ("Adam", "SGD"):
             raise ValueError(f"optimizer {self.optimizer!r} not supported: Adam or SGD (utils/utils.py:120-129)")
@@ -339,9 +388,18 @@ class PoseNetTrainer:
         for p in self.model.parameters():
             p.grad = None
 
-    def accumulate(self, fv, fi, timestamps, gts, hc=None, imu=None):
+    def accumulate(self, fv, fi, timestamps, gts, hc=None, imu=None, img=None):
         """forward -> loss -> backward of one batch, ADDING to the gradients already in ``param.grad`` (the reference's loop calls
-        ``loss.backward()`` every batch and steps every ``grad_accumulation_steps``-th, scripts/train_model.py:78-86)."""
+        ``loss.backward()`` every batch and steps every ``grad_accumulation_steps``-th, scripts/train_model.py:78-86).  ``img`` instead
+        of ``fv``: the image encoder is part of the graph (train mode; ``freeze_encoder`` off)."""
+        if img is not None:
+            if fv is not None:
+                raise ValueError("PoseNetTrainer.accumulate: pass fv or img, not both")
+            if self.freeze_encoder:
+                with torch.no_grad():
+                    fv = self.model.image_encoder(img)
+            else:
+                fv = image_encoder(self.model, img)
         if imu is not None:
             if fi is not None:
                 raise ValueError("PoseNetTrainer.accumulate: pass fi or imu, not both")
@@ -372,7 +430,8 @@ def train_epoch(model, trainer, loader, log=None, log_every=20):
     """One epoch of the reference's ``train()`` (scripts/train_model.py:48-95) on libodevio: ``loader`` yields
     ``(imgs [B,S,3,H,W], imus [B,10(S-1)+1,6], gts [B,S-1,6], timestamps [B,S], folder)`` like the reference's ``DataLoader``.
     Like the reference's epoch loop (:219) the model is put in ``train()``: both encoders run with batch-statistics BatchNorm and
-    Dropout (the frozen ``Image_net`` under ``no_grad``, the inertial encoder inside the graph); gradients accumulate over
+    Dropout (``Image_net`` under ``no_grad`` when ``opt.freeze_encoder``, else inside the graph so that its gradients count in the
+    clipping norm; the inertial encoder always inside the graph); gradients accumulate over
     ``opt.grad_accumulation_steps`` batches (and the last batch) before clip + step (:82-86); ``opt.optimizer`` picks Adam or SGD.
     Returns the mean pose loss like the reference.  ``log(message)`` receives the reference's per-iteration line."""
     losses = []
@@ -385,9 +444,7 @@ def train_epoch(model, trainer, loader, log=None, log_every=20):
         dev = next(model.parameters()).device
         imgs, imus = imgs.to(dev).float(), imus.to(dev).float()
         gts, timestamps = gts.to(dev).float(), timestamps.to(dev).float()
-        with torch.no_grad():
-            fv = model.image_encoder(imgs)
-        loss, _, _ = trainer.accumulate(fv, None, timestamps, gts, imu=imus)
+        loss, _, _ = trainer.accumulate(None, None, timestamps, gts, imu=imus, img=imgs)   # Image_net: no graph when frozen, else its backward
         if (i + 1) % accum == 0 or (i + 1) == n:
             trainer.apply_gradients()
             trainer.zero_all_grads()

@@ -242,6 +242,79 @@ def test_train_epoch_follows_torch_with_batchnorm_in_train_mode(optimizer, accum
             assert oc.rel_err(now[k], leaves[k]) < 2e-5, k
 
 
+@pytest.mark.parametrize("hw,B,S", [((64, 128), 2, 3), ((96, 160), 1, 3)])
+def test_image_encoder_backward_matches_autograd_through_the_oracle(hw, B, S):
+    """odevio_image_encoder_bwd: every Image_net parameter gradient (nine Conv2d weights, BatchNorm gamma / beta, the visual head)
+    against torch.autograd through the oracle's train-mode image encoder in float64, fed the device's dropout masks - Dropout,
+    LeakyReLU, batch-statistics BatchNorm backward, weight gradients (contraction over all pixels) and input gradients (stride-1
+    convolutions of the zero-dilated gradient with the reversed filters; 96 x 160: odd sizes in the deeper blocks)."""
+    H, W = hw
+    opt = default_opt(img_h=H, img_w=W)
+    model, sd = make_model(opt, seed=78)
+    model.train()
+    model.set_seed(41)
+    img = synth.images(B, S, H, W, seed=95)
+    g = torch.Generator().manual_seed(4)
+    wgt = torch.randn(B, S - 1, 512, generator=g)
+    names = train.image_param_names()
+    fv = train.image_encoder(model, img.cuda())
+    (fv * wgt.cuda()).sum().backward()
+    model.check()
+    leaves = {k: (v.clone().double().requires_grad_(k in names) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    ref = oc.image_encoder(leaves, img, dtype=torch.float64, train={}, masks=_image_masks(model, opt, 41, 0, B * (S - 1)))
+    (ref * wgt.double()).sum().backward()
+    assert_close(fv, ref, what="fv (train mode, kept for the backward)")
+    params = dict(model.named_parameters())
+    worst = {}
+    for n in names:
+        got, want = params[n].grad, leaves[n].grad
+        assert got is not None and got.shape == want.shape, n
+        worst[n] = float((got.cpu().double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+    bad = {n: e for n, e in worst.items() if e > 1e-3}
+    assert not bad, bad
+    with pytest.raises(ValueError):                                  # a backward needs ITS forward: another shape has nothing kept
+        from odevio_amd import _lib
+        arr = train._tensor_array(["Image_net.visual_head.bias"], [torch.empty(512, device="cuda")])
+        _lib.check(model._lib.odevio_image_encoder_bwd(model._plan, img.cuda().data_ptr(), B + 1, S, fv.data_ptr(), 512, arr, 1, model._stream()))
+
+
+def test_trainer_counts_image_encoder_gradients_in_the_clip_norm_when_not_frozen():
+    """freeze_encoder = False (the reference's DEFAULT flag value, scripts/config.py:32): loss.backward() reaches Image_net, whose
+    gradients count in clip_grad_norm_(model.parameters()) (scripts/train_model.py:84) while the optimizer still only holds Pose_net
+    (utils/utils.py:116-119).  One train_epoch step against the same loop on the oracle: the total norm (dominated by what Image_net
+    adds), the losses, and Image_net's weights untouched."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", freeze_encoder=False, gradient_clip=0.05, lr_warmup=1e-4)
+    model, sd = make_model(opt, seed=79)
+    model.set_seed(55)
+    B, S = 2, 3
+    P = B * (S - 1)
+    img, imu, ts = synth.batch(B, S, 64, 128, seed=66)
+    gts = torch.randn(B, S - 1, 6, generator=torch.Generator().manual_seed(5)) * torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    trainer = train.PoseNetTrainer(model)
+    out = []
+    train.train_epoch(model, trainer, [(img, imu, gts, ts, "synthetic")], log=out.append, log_every=1)
+    model.check()
+    dev_loss, dev_norm = float(out[0].split("pose loss: ")[1].split(",")[0]), float(trainer.grad_norm)
+    leaves = {k: (v.clone().float() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    names = [k for k in leaves if leaves[k].is_floating_point() and "running" not in k and k in dict(model.named_parameters())]
+    for n in names:
+        leaves[n].requires_grad_(True)
+    fv = oc.image_encoder(leaves, img, train={}, masks=_image_masks(model, opt, 55, 0, P))
+    fi = oc.inertial_encoder(leaves, imu, train={}, masks=_imu_masks(model, 55, 9, P, 0.0), p_drop=0.0)
+    poses, _ = oc.pose_ode_rnn(leaves, fv, fi, ts, None, opt)
+    loss = _loss(poses, gts)
+    loss.backward()
+    with_image = float(torch.nn.utils.clip_grad_norm_([leaves[n] for n in names], max_norm=0.05))
+    without = float(torch.sqrt(sum((leaves[n].grad.double() ** 2).sum() for n in names if not n.startswith("Image_net."))))
+    assert abs(dev_loss - float(loss)) <= 3e-4 * abs(float(loss)) + 1e-6
+    assert abs(dev_norm - with_image) <= 3e-3 * with_image, (dev_norm, with_image, without)
+    assert with_image > 1.05 * without                                # Image_net's share is visible: the frozen-encoder norm would be wrong
+    now = dict(model.named_parameters())
+    for n in names:
+        if n.startswith(("Image_net.", "Inertial_net.")):
+            assert torch.equal(now[n].detach().cpu(), sd[n]), n       # never the optimizer's
+
+
 def test_a_falsy_gradient_clip_means_no_update_like_the_reference():
     """scripts/train_model.py:83-86: `if args.gradient_clip: clip; optimizer.step()` - with gradient_clip = 0 the gradients are
     zeroed and nothing is updated."""
@@ -254,5 +327,3 @@ def test_a_falsy_gradient_clip_means_no_update_like_the_reference():
     before = [p.detach().clone() for p in trainer.params]
     trainer.step(fv, fi, ts, gts)
     assert all(torch.equal(a, b.detach()) for a, b in zip(before, trainer.params)) and trainer.steps == 0
-    with pytest.raises(NotImplementedError):
-        train.PoseNetTrainer(make_model(default_opt(img_h=64, img_w=128), seed=76)[0])           # freeze_encoder = False: refused
