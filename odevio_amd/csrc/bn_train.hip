@@ -50,20 +50,29 @@ __global__ __launch_bounds__(256) void bn_stats_p2_kernel(const unsigned char* _
   }
 }
 
-// one thread per channel: block partials in block order -> statistics -> affine pair; running statistics like torch
-__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int C, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one workgroup per channel: thread t sums block partials t, t + 256, ... in order, then a fixed tree -> statistics -> affine pair;
+// running statistics like torch  (a single thread per channel walking 1024 strided partials cost 0.26 ms per layer)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int C, double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  __shared__ double rs[256], rq[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = tid; b < nblk; b += 256) {
     s += partial[((size_t)b * C + c) * 2];
     q += partial[((size_t)b * C + c) * 2 + 1];
   }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
+  rs[tid] = s;
+  rq[tid] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) { rs[tid] += rs[tid + w]; rq[tid] += rq[tid + w]; }
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  const double mean = rs[0] / count;
+  double var = rq[0] / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * invstd;
@@ -153,7 +162,7 @@ hipError_t bn_stats_p2(const void* z, size_t M, int C, double* partial, const fl
   const int nblk = (int)std::min<size_t>(BN_MAX_BLOCKS, (M + PL - 1) / PL);
   (void)hipGetLastError();
   hipLaunchKernelGGL(bn_stats_p2_kernel, dim3(nblk), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(z), M, C, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblk, C, (double)M, gamma, beta, eps, momentum, run_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, (double)M, gamma, beta, eps, momentum, run_mean,
                      run_var, scale, shift, mean_out, invstd_out);
   return hipGetLastError();
 }

@@ -77,16 +77,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
   }
 }
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
+  __shared__ double rs[256], rq[256];
+  const int c = blockIdx.x, tid = threadIdx.x;   // one workgroup per channel, fixed summation tree
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = tid; b < nblk; b += 256) {
     s += partial[((size_t)b * C + c) * 2];
     q += partial[((size_t)b * C + c) * 2 + 1];
   }
-  sums[c] = (float)s;
-  sums[C + c] = (float)q;
+  rs[tid] = s;
+  rq[tid] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) { rs[tid] += rs[tid + w]; rq[tid] += rq[tid + w]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    sums[c] = (float)rs[0];
+    sums[C + c] = (float)rq[0];
+  }
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g_a, const unsigned char* __restrict__ z, size_t M, int C,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -263,7 +272,7 @@ hipError_t enc_bn_bwd_reduce(const float* g_a, const void* z, size_t M, int C, c
   (void)hipGetLastError();
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, g_a, reinterpret_cast<const unsigned char*>(z), M, C, mean, invstd, gamma,
                      beta, drop, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblk, C, sums);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, sums);
   return hipGetLastError();
 }
 

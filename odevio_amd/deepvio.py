@@ -191,6 +191,27 @@ class DeepVIO(nn.Module):
             sig.append((t.data_ptr(), t._version))
         return tuple(sig)
 
+    def _refresh_pose_net(self, old_sig, sig):
+        """True when the ONLY difference between two signatures is the version of Pose_net parameters (an in-place optimizer step
+        of torch.optim on them - what the reference's loop does, scripts/train_model.py:85) and the plan could be refreshed in place
+        (``odevio_plan_update``: device re-layout kernels, no host round trip) instead of being rebuilt."""
+        if old_sig is None or len(old_sig) != len(sig) or self.opt.model_type == "cde":
+            return False
+        named = list(self.named_parameters()) + list(self.named_buffers())
+        for (name, _), a, b in zip(named, old_sig, sig):
+            if a == b:
+                continue
+            if a[0] != b[0] or not name.startswith("Pose_net."):
+                return False                       # a tensor moved, or an encoder weight changed: the plan folds those at creation
+        from .train import fuse_param_names, pose_param_names, _tensor_array
+        names = fuse_param_names(self.opt) + pose_param_names(self.opt)
+        params = dict(self.named_parameters())
+        tensors = [params[n].detach() for n in names]
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+            return False
+        rc = self._lib.odevio_plan_update(self._plan, _tensor_array(names, tensors), len(tensors), self._stream())
+        return rc == _lib.ODEVIO_OK
+
     def _config(self):
         o = self.opt
         c = _lib.OdevioConfig()
@@ -218,7 +239,11 @@ class DeepVIO(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("odevio_amd.DeepVIO runs on an MI355X only: move the model with .cuda() (no CPU path)")
         sig = self._signature()
-        if self._plan is not None and sig == self._plan_sig and not (self._bn_dirty and not self.training):
+        stale_bn = self._bn_dirty and not self.training
+        if self._plan is not None and sig == self._plan_sig and not stale_bn:
+            return
+        if self._plan is not None and not stale_bn and self._refresh_pose_net(self._plan_sig, sig):
+            self._plan_sig = sig
             return
         self._bn_dirty = False
         # the random stream (hard fusion's Gumbel noise, train-mode dropout) belongs to the MODEL, not to one plan: a rebuild after
@@ -282,15 +307,25 @@ class DeepVIO(nn.Module):
         self._ensure_plan()
         if self.training:
             # model.train() (scripts/train_model.py:69,219): both encoders normalise with BATCH statistics, move their running
-            # statistics and apply Dropout - computed here as the reference computes it; what this forward does NOT carry is an
-            # autograd graph (gradients: odevio_amd.train.pose_net / PoseNetTrainer): said once
-            if torch.is_grad_enabled() and not self._warned_train:
-                import warnings
-                warnings.warn("odevio_amd.DeepVIO.forward in train(): train-mode BatchNorm / Dropout semantics, but no autograd graph; "
-                              "use odevio_amd.train (pose_net, PoseNetTrainer) for gradients", stacklevel=2)
-                self._warned_train = True
+            # statistics and apply Dropout - computed here as the reference computes it.  With gradients enabled the result carries
+            # an autograd graph whose nodes run in libodevio (odevio_amd.train), so the reference's own loop - loss.backward(),
+            # clip_grad_norm_(model.parameters()), a torch.optim step on Pose_net - works on this model unchanged.
             if img.dtype == torch.uint8:
                 raise ValueError("train mode takes the loader's float frames [B,S,3,H,W] (uint8 frames: eval mode)")
+            if torch.is_grad_enabled() and self.opt.model_type != "cde":
+                from . import train as _train
+                if any(q.requires_grad for q in self.Image_net.parameters()):
+                    fv = _train.image_encoder(self, img)
+                else:                               # --freeze_encoder (scripts/train_model.py:191-194): no graph through Image_net
+                    with torch.no_grad():
+                        fv = self.image_encoder(img)
+                fi = _train.imu_encoder(self, imu) if any(q.requires_grad for q in self.Inertial_net.parameters()) else self.imu_encoder(imu)
+                return _train.pose_net(self, fv, fi, timestamps, hc)
+            if torch.is_grad_enabled() and not self._warned_train:
+                import warnings
+                warnings.warn("odevio_amd.DeepVIO.forward (model_type cde) in train(): train-mode encoders, but the Neural-CDE path has no "
+                              "backward - the result carries no autograd graph", stacklevel=2)
+                self._warned_train = True
             fv, fi = self.image_encoder(img), self.imu_encoder(imu)
             if self.opt.model_type == "cde":
                 return self.pose_cde(fv, fi, timestamps, hc)

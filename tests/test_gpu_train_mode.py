@@ -315,6 +315,93 @@ def test_trainer_counts_image_encoder_gradients_in_the_clip_norm_when_not_frozen
             assert torch.equal(now[n].detach().cpu(), sd[n]), n       # never the optimizer's
 
 
+def test_the_reference_training_loop_runs_unchanged_on_this_model():
+    """The drop-in property for TRAINING: the body of the reference's train() (scripts/train_model.py:54-86) with the reference's own
+    optimizer factory (utils/utils.py:115-130: torch.optim.Adam over Pose_net's two parameter groups) and its --freeze_encoder lines
+    (:191-194), written here exactly as the reference writes them, runs on odevio_amd.DeepVIO: model(...) in train() returns poses
+    with an autograd graph whose nodes are libodevio calls, loss.backward() fills .grad, clip_grad_norm_(model.parameters()) and
+    optimizer.step() are PyTorch's own - and the next forward sees the stepped weights through an in-place plan refresh (the plan
+    object is never rebuilt).  Checked against the same loop on the oracle, fed the device's dropout masks."""
+    opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", freeze_encoder=True, weight_decay=5e-5, gradient_clip=5, lr_warmup=1e-4)
+    model, sd = make_model(opt, seed=87)
+    model.set_seed(3)
+    B, S = 2, 4
+    P = B * (S - 1)
+    scale = torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    train_loader = []
+    for k in range(3):
+        img, imu, ts = synth.batch(B, S, 64, 128, seed=110 + k)
+        train_loader.append((img, imu, torch.randn(B, S - 1, 6, generator=torch.Generator().manual_seed(k)) * scale, ts, "synthetic"))
+    args = opt
+    # ---- scripts/train_model.py:191-194
+    if args.freeze_encoder:
+        for param in model.Image_net.parameters():
+            param.requires_grad = False
+    # ---- utils/utils.py:115-130
+    param_groups = [{"params": model.Pose_net.get_other_params(), "lr": args.lr_warmup},
+                    {"params": model.Pose_net.get_regressor_params(), "lr": args.lr_warmup}]
+    optimizer = torch.optim.Adam(param_groups, lr=args.lr_warmup, betas=(0.9, 0.999), eps=1e-08, weight_decay=args.weight_decay)
+    # ---- scripts/train_model.py:219, :54-86
+    model.train()
+    mse_losses, plans = [], set()
+    data_len = len(train_loader)
+    optimizer.zero_grad()
+    for i, (imgs, imus, gts, timestamps, folder) in enumerate(train_loader):
+        imgs, imus, gts, timestamps = imgs.cuda().float(), imus.cuda().float(), gts.cuda().float(), timestamps.cuda().float()
+        poses, _ = model(imgs, imus, timestamps, hc=None)
+        angle_loss = torch.nn.functional.mse_loss(poses[:, :, :3], gts[:, :, :3])
+        translation_loss = torch.nn.functional.mse_loss(poses[:, :, 3:], gts[:, :, 3:])
+        pose_loss = 100 * angle_loss + translation_loss
+        loss = pose_loss
+        loss.backward()
+        if (i + 1) % args.grad_accumulation_steps == 0 or (i + 1) == data_len:
+            if args.gradient_clip:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=args.gradient_clip)
+                optimizer.step()
+            optimizer.zero_grad()
+        mse_losses.append(pose_loss.item())
+        plans.add(model._plan.value)
+    model.check()
+    assert len(plans) == 1, "a torch optimizer step on Pose_net must refresh the plan in place, not rebuild it"
+    # ---- the same loop on the oracle
+    inames = train.imu_param_names()
+    leaves = {k: (v.clone().float() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    pnames = [n for n, _ in model.named_parameters() if n.startswith("Pose_net.")]
+    params = [leaves[n].requires_grad_(True) for n in pnames]
+    iparams = [leaves[n].requires_grad_(True) for n in inames]
+    ref_opt = torch.optim.Adam(params, lr=args.lr_warmup, betas=(0.9, 0.999), eps=1e-08, weight_decay=args.weight_decay)
+    ref_losses = []
+    for i, (img, imu, gts, ts, _) in enumerate(train_loader):
+        new = {}
+        with torch.no_grad():
+            fv = oc.image_encoder(leaves, img, train=new, masks=_image_masks(model, opt, 3, 12 * i, P))
+        fi = oc.inertial_encoder(leaves, imu, train=new, masks=_imu_masks(model, 3, 12 * i + 9, P, 0.0), p_drop=0.0)
+        poses, _ = oc.pose_ode_rnn(leaves, fv, fi, ts, None, opt)
+        loss = _loss(poses, gts)
+        loss.backward()
+        leaves.update(new)
+        torch.nn.utils.clip_grad_norm_(params + iparams, max_norm=args.gradient_clip)
+        ref_opt.step()
+        ref_opt.zero_grad()
+        for q in iparams:
+            q.grad = None
+        ref_losses.append(float(loss.detach()))
+    for a, b in zip(mse_losses, ref_losses):
+        assert abs(a - b) <= 3e-4 * abs(b) + 1e-6, (mse_losses, ref_losses)
+    now = dict(model.named_parameters())
+    lr = args.lr_warmup
+    for n in pnames:
+        d = (now[n].detach().cpu() - leaves[n].detach()).abs()
+        assert float(d.max()) <= 1.0 * lr * 3 and float((d > 0.03 * lr).float().mean()) < 3e-3, n
+        assert not torch.equal(now[n].detach().cpu(), sd[n])         # it did train
+    # and eval mode afterwards computes on the trained weights and the moved running statistics
+    model.eval()
+    img, imu, ts = train_loader[0][0], train_loader[0][1], train_loader[0][3]
+    poses, _ = model(img.cuda(), imu.cuda(), ts.cuda())
+    ref, _ = oc.deepvio_forward({k: v.detach().cpu() for k, v in model.state_dict().items()}, img, imu, ts, None, opt)
+    assert_close(poses, ref, what="poses (eval after the reference's loop)")
+
+
 def test_a_falsy_gradient_clip_means_no_update_like_the_reference():
     """scripts/train_model.py:83-86: `if args.gradient_clip: clip; optimizer.step()` - with gradient_clip = 0 the gradients are
     zeroed and nothing is updated."""
