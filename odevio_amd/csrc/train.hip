@@ -37,9 +37,31 @@
 //   NT: out[m][n] (+)= sum_k A[m * lda + k] * W[n * ldw + k] (+ bias[n])          K % 4 == 0, lda % 4 == 0, ldw % 4 == 0
 //   TN: out[n][k] (+)= sum_m D[m * ldd + n] * A[m * lda + k]                      (weight gradients: contraction over rows)
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tr_act(float v, int act) {   // ODEFunc.py:23-36 (LeakyReLU default slope 0.01)
+  switch (act) {
+    case 0: return tanhf(v);
+    case 1: return fmaxf(v, 0.f);
+    case 2: return v > 0.f ? v : 0.01f * v;
+    default: return v > 20.f ? v : log1pf(expf(v));
+  }
+}
+// derivative expressed through the activation's OUTPUT a (what the tape keeps)
+__device__ __forceinline__ float tr_act_grad(float a, int act) {
+  switch (act) {
+    case 0: return 1.f - a * a;
+    case 1: return a > 0.f ? 1.f : 0.f;
+    case 2: return a > 0.f ? 1.f : 0.01f;
+    default: return a > 20.f ? 1.f : -expm1f(-a);   // softplus: sigmoid(z) = 1 - exp(-a)
+  }
+}
+
+// Epilogues of the NT product (fused so that a layer of the tape / of the reverse sweep is ONE launch, not two):
+//   EPI_ACT: out = act(sum + bias)  - the ODEFunc layer itself;   EPI_DACT: out = sum * act'(aux[m][n]) - the layer's adjoint, aux = the
+//   activation's saved OUTPUT (what the tape keeps).  Same arithmetic, in the same order, as the separate element-wise kernels.
+enum GemmEpi { GEPI_NONE = 0, GEPI_ACT = 1, GEPI_DACT = 2 };
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                       const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
-                                                      int accumulate) {
+                                                      int accumulate, int epi, int act, const float* __restrict__ aux, int ldaux) {
   __shared__ float red[4][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -64,6 +86,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   if (n < N && m < M) {
     float v = (red[0][nl][ml] + red[1][nl][ml]) + (red[2][nl][ml] + red[3][nl][ml]);
     if (bias) v += bias[n];
+    if (epi == GEPI_ACT) v = tr_act(v, act);
+    else if (epi == GEPI_DACT) v *= tr_act_grad(aux[(size_t)m * ldaux + n], act);
     float* o = out + (size_t)m * ldo + n;
     *o = accumulate ? *o + v : v;
   }
@@ -100,9 +124,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 }
 
 static void gemm_nt(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N,
-                    int K, bool accumulate = false) {
+                    int K, bool accumulate = false, int epi = GEPI_NONE, int act = 0, const float* aux = nullptr, int ldaux = 0) {
   hipLaunchKernelGGL(gemm_nt_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K,
-                     accumulate ? 1 : 0);
+                     accumulate ? 1 : 0, epi, act, aux, ldaux);
 }
 static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K,
                     bool accumulate = false) {
@@ -114,24 +138,6 @@ static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int
 // ---------------------------------------------------------------------------------------------------------------------
 #define EW_GRID(n) dim3((unsigned)std::min<size_t>(((size_t)(n) + 255) / 256, 4096)), dim3(256)
 #define EW_LOOP(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); i += (size_t)gridDim.x * blockDim.x)
-
-__device__ __forceinline__ float tr_act(float v, int act) {   // ODEFunc.py:23-36 (LeakyReLU default slope 0.01)
-  switch (act) {
-    case 0: return tanhf(v);
-    case 1: return fmaxf(v, 0.f);
-    case 2: return v > 0.f ? v : 0.01f * v;
-    default: return v > 20.f ? v : log1pf(expf(v));
-  }
-}
-// derivative expressed through the activation's OUTPUT a (what the tape keeps)
-__device__ __forceinline__ float tr_act_grad(float a, int act) {
-  switch (act) {
-    case 0: return 1.f - a * a;
-    case 1: return a > 0.f ? 1.f : 0.f;
-    case 2: return a > 0.f ? 1.f : 0.01f;
-    default: return a > 20.f ? 1.f : -expm1f(-a);   // softplus: sigmoid(z) = 1 - exp(-a)
-  }
-}
 
 __global__ void act_kernel(float* x, size_t n, int act) { EW_LOOP(i, n) x[i] = tr_act(x[i], act); }
 
@@ -365,7 +371,7 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
   float* lam = q; q += RF;
   float* gX = q; q += RF;
   float* lamK = q; q += 8 * RF;
-  float* gs = q; q += (size_t)R * std::max(F, m.H);
+  q += (size_t)R * std::max(F, m.H);   // (scratch of the unfused reverse sweep; the layout of the workspace is kept)
   const int G = m.gru ? 3 : 1, GF = G * F;     // gate rows per hidden unit
   float *rnn_in[TRAIN_MAX_L], *rnn_hp[TRAIN_MAX_L], *rnn_out[TRAIN_MAX_L], *rnn_delta[TRAIN_MAX_L];
   float *rnn_delta_h[TRAIN_MAX_L] = {}, *rnn_gates[TRAIN_MAX_L] = {};
@@ -407,8 +413,8 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
           hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, act[0] + m0 * F, Y, kbase, RF, arow[s], dtp, R, F);
           for (int l = 0; l < nl; ++l) {
             float* o = act[l + 1] + m0 * m.dims[l + 1];
-            gemm_nt(st, act[l] + m0 * m.dims[l], m.dims[l], m.ode_w[l], m.dims[l], m.ode_b[l], o, m.dims[l + 1], R, m.dims[l + 1], m.dims[l]);
-            hipLaunchKernelGGL(act_kernel, EW_GRID((size_t)R * m.dims[l + 1]), 0, st, o, (size_t)R * m.dims[l + 1], l + 1 < nl ? m.act : 0);
+            gemm_nt(st, act[l] + m0 * m.dims[l], m.dims[l], m.ode_w[l], m.dims[l], m.ode_b[l], o, m.dims[l + 1], R, m.dims[l + 1], m.dims[l], false,
+                    GEPI_ACT, l + 1 < nl ? m.act : 0);   // Linear + activation (the last one: Tanh, ODEFunc.py:13-14) in one launch
           }
         }
         // Y <- Y + dt * sum_s b_s K_s: the stage-input formula with the b row
@@ -470,9 +476,9 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
           // K_s = tanh(.) : delta of the last Linear
           hipLaunchKernelGGL(act_bwd_kernel, EW_GRID(RF), 0, st, lamK + (size_t)s * RF, act[nl] + m0 * F, delta[nl - 1] + m0 * F, RF, 0);
           for (int l = nl - 1; l >= 1; --l) {
-            gemm_nt(st, delta[l] + m0 * m.dims[l + 1], m.dims[l + 1], m.ode_w_t[l], m.dims[l + 1], nullptr, gs, m.dims[l], R, m.dims[l], m.dims[l + 1]);
-            hipLaunchKernelGGL(act_bwd_kernel, EW_GRID((size_t)R * m.dims[l]), 0, st, gs, act[l] + m0 * m.dims[l], delta[l - 1] + m0 * m.dims[l],
-                               (size_t)R * m.dims[l], m.act);
+            // delta_{l-1} = (delta_l W_l) * act'(saved activation): one launch
+            gemm_nt(st, delta[l] + m0 * m.dims[l + 1], m.dims[l + 1], m.ode_w_t[l], m.dims[l + 1], nullptr, delta[l - 1] + m0 * m.dims[l], m.dims[l], R,
+                    m.dims[l], m.dims[l + 1], false, GEPI_DACT, m.act, act[l] + m0 * m.dims[l], m.dims[l]);
           }
           gemm_nt(st, delta[0] + m0 * m.dims[1], m.dims[1], m.ode_w_t[0], m.dims[1], nullptr, gX, F, R, F, m.dims[1]);
           hipLaunchKernelGGL(stage_adjoint_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, gX, arow[s], dtp, R, F);
