@@ -160,6 +160,16 @@ int odevio_ode_rnn_fwd(odevio_plan* plan, const float* fused, const float* ts, c
  * stats_host = {steps, accepted} or NULL. */
 int odevio_cde_fwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, const double* t_out_host, int32_t n_out,
                    const float* z0_in, float* poses, float* z0_out, int32_t* stats_host, void* stream);
+/* Backward of odevio_cde_fwd - loss.backward() through PoseCDE.forward with adjoint = False (PoseCDE.py:98-101: autograd through
+ * torchcde's cdeint -> torchdiffeq's odeint): the solve is run once more with a tape of its accepted steps and swept in reverse
+ * (discretise-then-optimise; step sizes are constants of the differentiation; dense-output interpolation, knot re-evaluations and
+ * the three solvers included).  torchcde / torchdiffeq are absent offline: checked against autograd through the oracle's
+ * restatement, parity with the real libraries UNPINNED.  grad_poses [B,n_out,6]; grad_z0_out (or NULL): gradient of the returned z0;
+ * grad_obs [B,L,1+F] out (channel 0 = the time channel); grad_z0_in out when z0_in is given.  grads: "Pose_net.cde_func.net.<2l>.weight /
+ * .bias", "Pose_net.initial.0.*", "Pose_net.regressor.{0,2}.*".  One host read (the tape's step records).  fp32 plans only. */
+int odevio_cde_bwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, const double* t_out_host, int32_t n_out, const float* z0_in,
+                   const float* grad_poses, const float* grad_z0_out, float* grad_obs, float* grad_z0_in, const odevio_tensor* grads,
+                   int32_t n_grads, int32_t* stats_host, void* stream);
 /* Backward of odevio_ode_rnn_fwd: what `loss.backward()` reaches below the encoders in the reference's training step
  * (scripts/train_model.py:69-78; autograd through torchode's AutoDiffAdjoint = backpropagation through the solver's own
  * operations, "discretise-then-optimise").  Inputs as in the forward plus grad_poses [B,P,6] and grad_hT [L,B,F] or NULL;

@@ -28,7 +28,7 @@ SYMBOLS = [
     "odevio_fuse_bwd", "odevio_grad_clip", "odevio_adam_step", "odevio_plan_update", "odevio_imu_encoder_bwd", "odevio_set_seed",
     "odevio_rng_state", "odevio_debug_gumbel", "odevio_fuse_hard_bwd", "odevio_set_rng_state",
     "odevio_image_encoder_fwd_train", "odevio_imu_encoder_fwd_train", "odevio_imu_encoder_bwd_train", "odevio_debug_dropout",
-    "odevio_sgd_step", "odevio_image_encoder_bwd",
+    "odevio_sgd_step", "odevio_image_encoder_bwd", "odevio_cde_bwd",
 ]
 
 
@@ -109,6 +109,7 @@ def load():
     lib.odevio_ode_rnn_fwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, vp, vp]
     lib.odevio_cde_fwd.argtypes = [vp, fp, i32, i32, vp, i32, fp, fp, fp, vp, vp]
     lib.odevio_cde_last_ms.argtypes = [vp, fp]
+    lib.odevio_cde_bwd.argtypes = [vp, fp, i32, i32, vp, i32, fp, fp, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp, vp]
     lib.odevio_ode_rnn_bwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_pose_loss.argtypes = [fp, fp, i32, fp, fp, vp]
     f32 = ctypes.c_float

@@ -19,6 +19,7 @@
 #include "train.h"
 #include "bn_train.h"
 #include "enc_bwd.h"
+#include "cde_bwd.h"
 
 // roctx ranges at the two sites the reference marks with NVTX (src/models/PoseODERNN.py:103-104 "ODE", :118-119 "RNN"),
 // plus the encoders: visible in rocprofv3 --marker-trace.  libroctx64 is looked up at run time (no link dependency);
@@ -1836,6 +1837,70 @@ extern "C" int odevio_cde_fwd(odevio_plan* p, const float* obs, int32_t B, int32
   rc = regress(p, sol, B * n_out, poses, st);
   post_status(p, st);
   return rc;
+}
+
+// Backward of odevio_cde_fwd (cde_bwd.hip): the solve is run once more with a tape, then swept in reverse.
+extern "C" int odevio_cde_bwd(odevio_plan* p, const float* obs, int32_t B, int32_t L, const double* t_out_host, int32_t n_out, const float* z0_in,
+                              const float* grad_poses, const float* grad_z0_out, float* grad_obs, float* grad_z0_in, const odevio_tensor* grads,
+                              int32_t n_grads, int32_t* stats_host, void* stream) {
+  ARGCHK(p && obs && t_out_host && grad_poses && grad_obs && B > 0 && L > 1 && n_out > 0 && n_grads >= 0 && (grads || n_grads == 0),
+         "odevio_cde_bwd: bad argument");
+  if (p->cfg.model_type != ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "plan is not a Neural-CDE plan");
+  if (p->cde.w_last16) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_cde_bwd: the reduced-precision (bf16 last layer) plan has no backward; use --dtype fp32");
+  if (grad_z0_in && !z0_in) return fail(ODEVIO_ERR_BAD_ARG, "odevio_cde_bwd: grad_z0_in without z0_in");
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  const int H = p->cde.H, C = p->cde.C, n = B * H, nh = p->cde.n_hidden;
+  CdeBwdGrads g;
+  memset(&g, 0, sizeof(g));
+  for (int i = 0; i < n_grads; ++i) {
+    if (!grads[i].name || !grads[i].data) return fail(ODEVIO_ERR_BAD_ARG, "odevio_cde_bwd: gradient %d has no name / pointer", i);
+    const std::string nm = grads[i].name;
+    float* dst = (float*)grads[i].data;
+    int64_t want = -1;
+    for (int l = 0; l <= nh && want < 0; ++l) {
+      const std::string pre = "Pose_net.cde_func.net." + std::to_string(2 * l);
+      const int64_t N = l < nh ? H : (int64_t)H * C;
+      if (nm == pre + ".weight") { g.w[l] = dst; want = N * H; }
+      else if (nm == pre + ".bias") { g.b[l] = dst; want = N; }
+    }
+    if (want < 0) {
+      if (nm == "Pose_net.initial.0.weight") { g.init_w = dst; want = (int64_t)H * C; }
+      else if (nm == "Pose_net.initial.0.bias") { g.init_b = dst; want = H; }
+      else if (nm == "Pose_net.regressor.0.weight") { g.reg_w0 = dst; want = (int64_t)128 * H; }
+      else if (nm == "Pose_net.regressor.0.bias") { g.reg_b0 = dst; want = 128; }
+      else if (nm == "Pose_net.regressor.2.weight") { g.reg_w2 = dst; want = 6 * 128; }
+      else if (nm == "Pose_net.regressor.2.bias") { g.reg_b2 = dst; want = 6; }
+    }
+    if (want < 0) return fail(ODEVIO_ERR_BAD_ARG, "odevio_cde_bwd: '%s' is not a parameter of the Neural-CDE pose net", nm.c_str());
+    if (want != grads[i].numel) return fail(ODEVIO_ERR_BAD_ARG, "odevio_cde_bwd: gradient '%s' has the wrong size", nm.c_str());
+    // CDEFunc's gradients accumulate over the vector-field evaluations: start from zero.  z0_in given: the initial layer is not on the path
+    HIPCHK(hipMemsetAsync(dst, 0, (size_t)want * sizeof(float), st));
+  }
+  const int cap = std::max(16, std::min(p->cfg.max_steps, 1024));
+  int rc;
+  const size_t head = (512 + (size_t)n_out * sizeof(double) + 15) / 16 * 4;
+  const size_t need = head + 18 * (size_t)n + (size_t)B * n_out * H;
+  if ((rc = ensure(p->cde_ws, need)) || (rc = ensure(p->train_ws, cde_bwd_workspace_floats(p->cde, B, n_out, cap)))) return rc;
+  if (!p->cde_ctl_host) HIPCHK(hipHostMalloc((void**)&p->cde_ctl_host, sizeof(CdeCtl), hipHostMallocDefault));
+  float* q = p->cde_ws.p;
+  CdeWork w;
+  w.ctl = reinterpret_cast<CdeCtl*>(q);
+  w.t_out = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(q) + 512);
+  w.ctl_host = p->cde_ctl_host;
+  q += head;
+  w.ha = q; q += n; w.hb = q; q += n; w.ytmp = q; q += n; w.y = q; q += n; w.y1 = q; q += n;
+  w.k = q; q += 7 * (size_t)n;
+  w.interp = q; q += 5 * (size_t)n;
+  p->cde.n_cu = p->n_cu;
+  int stats[2] = {0, 0};
+  rc = cde_backward(p->cde, w, p->train_ws.p, obs, B, L, t_out_host, n_out, z0_in, p->cde_init_w, p->cde_init_b, p->reg_w0, p->train.reg_w0_t,
+                    p->reg_b0, p->reg_w2, grad_poses, grad_z0_out, grad_obs, grad_z0_in, g, cap, stats, st);
+  if (stats_host) { stats_host[0] = stats[0]; stats_host[1] = stats[1]; }
+  if (rc == ODEVIO_ERR_MAX_STEPS) return fail(rc, "odevio_cde_bwd: more than %d accepted steps (the tape's capacity) or the step budget exhausted", cap);
+  if (rc == ODEVIO_ERR_BAD_ARG) return fail(rc, "cdeint: output times must be strictly ascending");
+  if (rc) return fail(rc, "odevio_cde_bwd failed: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -92,5 +92,6 @@ void cde_launch_ctl_update(CdeCtl* ctl, const double* t_out, hipStream_t st);
 // Solves dz/dt = CDEFunc(z) . dX/dt from t_out[0], writing z(t_out[p]) to sol[b][p][:].  Fixed-grid solvers never
 // synchronise; the adaptive one reads the controller's `done` word once per BATCH of enqueued attempts (not per step).
 // Returns 0 or a negative odevio_status; stats = {steps, accepted}.  `hint_steps`: expected attempts (0 = unknown).
+struct CdeTape;   // cde_bwd.h: when given, every accepted step is recorded for the backward
 int cde_solve(const CdeModel& m, const CdeWork& w, const float* obs, int B, int L, const double* t_out, int n_out,
-              const float* z0, float* sol, int* stats, int hint_steps, hipStream_t st);
+              const float* z0, float* sol, int* stats, int hint_steps, hipStream_t st, const CdeTape* tape = nullptr);

@@ -14,6 +14,7 @@
 
 #include "../../include/odevio.h"
 #include "cde.h"
+#include "cde_bwd.h"
 
 namespace {
 
@@ -58,7 +59,7 @@ float f32_prev(float t) { return std::nextafterf(t, t - 1.0f); }
 }  // namespace
 
 int cde_solve(const CdeModel& m, const CdeWork& w, const float* obs, int B, int L, const double* t_out, int n_out,
-              const float* z0, float* sol, int* stats, int hint_steps, hipStream_t st) {
+              const float* z0, float* sol, int* stats, int hint_steps, hipStream_t st, const CdeTape* tape) {
   const int n = B * m.H;
   Field F{m, w, obs, B, L, st};
   auto kj = [&](int j) { return w.k + (size_t)j * n; };
@@ -87,6 +88,11 @@ int cde_solve(const CdeModel& m, const CdeWork& w, const float* obs, int B, int 
         cde_launch_combine(nullptr, 0, y, nullptr, 0, w.k, CdeCoefs{{0.125, 0.375, 0.375, 0.125}}, 4, dt, 0, y1, 0, n, st);
       }
       if (rc) return ODEVIO_ERR_HIP;
+      if (tape) {   // the step's state and stage derivatives for the backward (the host knows the rest of a fixed-grid step)
+        if (p - 1 >= tape->cap) return ODEVIO_ERR_MAX_STEPS;
+        (void)hipMemcpyAsync(tape->y + (size_t)(p - 1) * n, y, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(tape->k + (size_t)(p - 1) * 7 * n, w.k, (size_t)(m.solver == 2 ? 1 : 4) * n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      }
       std::swap(y, y1);
       cde_launch_emit_copy(y, sol, B, m.H, n_out, p, st);
       ++n_steps;
@@ -117,6 +123,7 @@ int cde_solve(const CdeModel& m, const CdeWork& w, const float* obs, int B, int 
       rc |= F.eval(CdeWhen{w.ctl, i, 0, 0}, w.ytmp, kj(i));
     }
     cde_launch_err_ratio(w.ctl, w.y, w.y1, w.k, DP_E, m.atol, m.rtol, n, st);
+    if (tape) cde_launch_tape_record(w.ctl, w.t_out, w.y, w.y1, w.k, *tape, n, n_out, st);   // before step_finish's FSAL copy overwrites k0
     cde_launch_step_finish(w.ctl, w.t_out, w.y, w.y1, w.k, DP_MID, w.interp, sol, B, m.H, n_out, st);
     cde_launch_ctl_update(w.ctl, w.t_out, st);
     // f on the far side of a jump (only if the accepted step ended on a knot): argument = the new y, result -> slot 0

@@ -93,8 +93,17 @@ int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, 
                   hipStream_t st);
 void skinny_linear(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, hipStream_t st);
 // out [N][K] (ldo) = sum over M rows of D[m][n] * A[m][k] (weight gradients: contraction over rows); out [N] = column sums of x [M][N]
-void skinny_tn(const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K, hipStream_t st);
+void skinny_tn(const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K, hipStream_t st, int accumulate = 0);
+// the same contraction split over `splits` row ranges (partial: splits * N * K floats), for M in the millions
+void skinny_tn_split(const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K, float* partial, int splits,
+                     int accumulate, hipStream_t st);
+// out [M][N] (+)= A W^T (+ bias) with an optional fused epilogue: epi 0 none, 1 out = act(.) (ODEFunc.py's activations: 0 tanh, 1 relu,
+// 2 leaky_relu 0.01, 3 softplus), 2 out = (.) * act'(aux[m][n]) with aux = the activation's saved OUTPUT.  K % 4 == 0.
+void skinny_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, int accumulate,
+               int epi, int act, const float* aux, int ldaux, hipStream_t st);
 void colsum_rows(const float* x, float* out, int M, int N, hipStream_t st);
+int train_regressor_bwd(const float* seq, int F, const float* w0, const float* w0_t, const float* b0, const float* w2, const float* g_poses, int M,
+                        float* ws, float* g_seq, float* g_w0, float* g_b0, float* g_w2, float* g_b2, hipStream_t st);
 void leaky_inplace(float* x, size_t n, float slope, hipStream_t st);
 void mul_inplace(float* x, const float* y, size_t n, hipStream_t st);   // x *= y
 int train_fuse_hard_bwd(const float* W, const float* W_t, const float* bias, float* cat, float* logits, float* g_logits, float* g_cat,

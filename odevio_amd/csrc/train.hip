@@ -1017,10 +1017,73 @@ int train_imu_bwd_train(const ImuTrain& m, const ImuTrainMode& tm, float* ws, co
 void skinny_linear(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, hipStream_t st) {
   gemm_nt(st, A, lda, W, ldw, bias, out, ldo, M, N, K);
 }
-void skinny_tn(const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K, hipStream_t st) {
-  gemm_tn(st, D, ldd, A, lda, out, ldo, M, N, K);
+void skinny_tn(const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K, hipStream_t st, int accumulate) {
+  gemm_tn(st, D, ldd, A, lda, out, ldo, M, N, K, accumulate != 0);
+}
+void skinny_nt(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N, int K, int accumulate,
+               int epi, int act, const float* aux, int ldaux, hipStream_t st) {
+  gemm_nt(st, A, lda, W, ldw, bias, out, ldo, M, N, K, accumulate != 0, epi, act, aux, ldaux);
+}
+// The TN product with the contraction (M rows) split over `splits` workgroup layers: partial [splits][N][K] slabs, combined in slab
+// order (deterministic).  For contractions over millions of rows with a 16-wide output (the Neural-CDE last layer's adjoint).
+__global__ __launch_bounds__(256) void gemm_tn_split_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ A, int lda,
+                                                            float* __restrict__ partial, int M, int N, int K, int rows_per_split) {
+  __shared__ float red[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  const int nn = min(n0 + r, N - 1), kk = min(k0 + r, K - 1);
+  const int m_begin = blockIdx.z * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int mb = m_begin + 16 * wave; mb < m_end; mb += 64) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + 4 * q + j;
+      const float dv = m < m_end ? D[(size_t)m * ldd + nn] : 0.f;
+      const float av = m < m_end ? A[(size_t)m * lda + kk] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, av, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];
+  __syncthreads();
+  const int nl = tid >> 4, kl = tid & 15;
+  const int n = n0 + nl, k = k0 + kl;
+  if (n < N && k < K)
+    partial[((size_t)blockIdx.z * N + n) * K + k] = (red[0][nl][kl] + red[1][nl][kl]) + (red[2][nl][kl] + red[3][nl][kl]);
+}
+__global__ void split_combine_kernel(const float* __restrict__ partial, float* __restrict__ out, int ldo, int N, int K, int splits, int accumulate) {
+  EW_LOOP(i, (size_t)N * K) {
+    const int n = (int)(i / K), k = (int)(i - (size_t)n * K);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(size_t)z * N * K + i];
+    float* o = out + (size_t)n * ldo + k;
+    *o = accumulate ? *o + s : s;
+  }
+}
+void skinny_tn_split(const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K, float* partial, int splits,
+                     int accumulate, hipStream_t st) {
+  const int rows = ((M + splits - 1) / splits + 15) / 16 * 16;
+  splits = (M + rows - 1) / rows;
+  hipLaunchKernelGGL(gemm_tn_split_kernel, dim3((K + 15) / 16, (N + 15) / 16, splits), dim3(256), 0, st, D, ldd, A, lda, partial, M, N, K, rows);
+  hipLaunchKernelGGL(split_combine_kernel, EW_GRID((size_t)N * K), 0, st, partial, out, ldo, N, K, splits, accumulate);
 }
 void colsum_rows(const float* x, float* out, int M, int N, hipStream_t st) { launch_colsum(st, x, out, M, N); }
+// regressor Linear(F,128) + LeakyReLU(0.1) + Linear(128,6) (PoseODERNN.py:64-68 / PoseCDE.py:68-72) backward from g_poses [M][6]:
+// g_seq [M][F] and the four parameter gradients (null = not wanted).  ws: 2 * M * 128 floats.
+int train_regressor_bwd(const float* seq, int F, const float* w0, const float* w0_t, const float* b0, const float* w2, const float* g_poses, int M,
+                        float* ws, float* g_seq, float* g_w0, float* g_b0, float* g_w2, float* g_b2, hipStream_t st) {
+  float *hid = ws, *dhid = ws + (size_t)M * 128;
+  gemm_nt(st, seq, F, w0, F, b0, hid, 128, M, 128, F);
+  hipLaunchKernelGGL(leaky_kernel, EW_GRID((size_t)M * 128), 0, st, hid, (size_t)M * 128, 0.1f);
+  hipLaunchKernelGGL(reg2_bwd_kernel, EW_GRID((size_t)M * 128), 0, st, g_poses, w2, hid, dhid, M);
+  if (g_seq) gemm_nt(st, dhid, 128, w0_t, 128, nullptr, g_seq, F, M, F, 128);
+  if (g_w0) gemm_tn(st, dhid, 128, seq, F, g_w0, F, M, 128, F);
+  if (g_b0) launch_colsum(st, dhid, g_b0, M, 128);
+  if (g_w2) gemm_tn(st, g_poses, 6, hid, 128, g_w2, 128, M, 6, 128);
+  if (g_b2) launch_colsum(st, g_poses, g_b2, M, 6);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}
 void leaky_inplace(float* x, size_t n, float slope, hipStream_t st) { hipLaunchKernelGGL(leaky_kernel, EW_GRID(n), 0, st, x, n, slope); }
 __global__ void mul_kernel(float* x, const float* y, size_t n) { EW_LOOP(i, n) x[i] *= y[i]; }
 void mul_inplace(float* x, const float* y, size_t n, hipStream_t st) { hipLaunchKernelGGL(mul_kernel, EW_GRID(n), 0, st, x, y, n); }

@@ -312,7 +312,7 @@ class DeepVIO(nn.Module):
             # clip_grad_norm_(model.parameters()), a torch.optim step on Pose_net - works on this model unchanged.
             if img.dtype == torch.uint8:
                 raise ValueError("train mode takes the loader's float frames [B,S,3,H,W] (uint8 frames: eval mode)")
-            if torch.is_grad_enabled() and self.opt.model_type != "cde":
+            if torch.is_grad_enabled():
                 from . import train as _train
                 if any(q.requires_grad for q in self.Image_net.parameters()):
                     fv = _train.image_encoder(self, img)
@@ -320,12 +320,11 @@ class DeepVIO(nn.Module):
                     with torch.no_grad():
                         fv = self.image_encoder(img)
                 fi = _train.imu_encoder(self, imu) if any(q.requires_grad for q in self.Inertial_net.parameters()) else self.imu_encoder(imu)
+                if self.opt.model_type == "cde":
+                    if getattr(self.opt, "dtype", "fp32") in ("fp16", "bf16"):
+                        raise ValueError("training the Neural-CDE path needs --dtype fp32 (the bf16 weight stream has no backward)")
+                    return _train.pose_cde(self, fv, fi, timestamps, hc)
                 return _train.pose_net(self, fv, fi, timestamps, hc)
-            if torch.is_grad_enabled() and not self._warned_train:
-                import warnings
-                warnings.warn("odevio_amd.DeepVIO.forward (model_type cde) in train(): train-mode encoders, but the Neural-CDE path has no "
-                              "backward - the result carries no autograd graph", stacklevel=2)
-                self._warned_train = True
             fv, fi = self.image_encoder(img), self.imu_encoder(imu)
             if self.opt.model_type == "cde":
                 return self.pose_cde(fv, fi, timestamps, hc)

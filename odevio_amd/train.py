@@ -267,6 +267,78 @@ def pose_net(model, fv, fi, timestamps, hc=None):
     return _OdeRnnFunction.apply(model, names, fused, timestamps, hc, *plist)
 
 
+def cde_param_names(opt):
+    """Parameters of the Neural-CDE pose net that are on its path (PoseCDE.py:59-72; ``reduction_net`` is constructed but never applied)."""
+    names = []
+    for l in range(opt.cde_fn_num_layers + 1):
+        names += [f"Pose_net.cde_func.net.{2 * l}.weight", f"Pose_net.cde_func.net.{2 * l}.bias"]
+    names += ["Pose_net.initial.0.weight", "Pose_net.initial.0.bias"]
+    return names + [f"Pose_net.regressor.{i}.{w}" for i in (0, 2) for w in ("weight", "bias")]
+
+
+class _CdeFunction(torch.autograd.Function):
+    """(obs [B,L,1+F], z0_in [B,H] | None, *parameters) -> (poses [B,n_out,6], z0 [B,H]): cdeint + regressor (PoseCDE.py:94-103) with the
+    backward of ``odevio_cde_bwd`` (the solve re-run with a tape, then swept in reverse).  ``t_out``: float64 host tensor."""
+
+    @staticmethod
+    def forward(ctx, model, names, t_out, obs, z0_in, *params):
+        obs = obs.detach().contiguous().float()
+        z0d = None if z0_in is None else z0_in.detach().contiguous().float()
+        B, L, C = obs.shape
+        hc = model.opt.cde_hidden_dim
+        n_out = t_out.numel()
+        poses = torch.empty(B, n_out, 6, device=obs.device, dtype=torch.float32)
+        z0 = torch.empty(B, hc, device=obs.device, dtype=torch.float32)
+        stats = (ctypes.c_int32 * 2)()
+        _lib.check(model._lib.odevio_cde_fwd(model._plan, obs.data_ptr(), B, L, t_out.data_ptr(), n_out, None if z0d is None else z0d.data_ptr(),
+                                             poses.data_ptr(), z0.data_ptr(), ctypes.cast(stats, ctypes.c_void_p), model._stream()))
+        ctx.model, ctx.names, ctx.t_out, ctx.has_z0 = model, names, t_out, z0d is not None
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(obs, *([z0d] if z0d is not None else []))
+        return poses, z0
+
+    @staticmethod
+    def backward(ctx, g_poses, g_z0):
+        model = ctx.model
+        saved = ctx.saved_tensors
+        obs = saved[0]
+        z0d = saved[1] if ctx.has_z0 else None
+        B, L, C = obs.shape
+        n_out = ctx.t_out.numel()
+        g_poses = torch.zeros(B, n_out, 6, device=obs.device) if g_poses is None else g_poses.contiguous().float()
+        g_z0 = None if g_z0 is None else g_z0.contiguous().float()
+        g_obs = torch.empty_like(obs)
+        g_z0_in = torch.empty_like(z0d) if z0d is not None else None
+        grads = [torch.empty(s, device=obs.device, dtype=torch.float32) for s in ctx.param_shapes]
+        model._ensure_plan()
+        _lib.check(model._lib.odevio_cde_bwd(model._plan, obs.data_ptr(), B, L, ctx.t_out.data_ptr(), n_out, None if z0d is None else z0d.data_ptr(),
+                                             g_poses.data_ptr(), None if g_z0 is None else g_z0.data_ptr(), g_obs.data_ptr(),
+                                             None if g_z0_in is None else g_z0_in.data_ptr(), _tensor_array(ctx.names, grads), len(grads), None,
+                                             model._stream()))
+        return (None, None, None, g_obs, g_z0_in, *grads)
+
+
+def pose_cde(model, fv, fi, timestamps, prev=None):
+    """``model.Pose_net`` forward for ``model_type cde`` (PoseCDE.forward, reference PoseCDE.py:76-103) in TRAINING mode WITH an autograd
+    graph: relative timestamps, no window history (:81-92), gradients to ``fv``, ``fi``, ``prev`` and every parameter on the path."""
+    opt = model.opt
+    if opt.model_type != "cde":
+        raise ValueError("odevio_amd.train.pose_cde: model_type must be cde")
+    if not model.training:
+        raise RuntimeError("odevio_amd.train.pose_cde: training mode only (eval mode accumulates a window history and carries no graph)")
+    model._ensure_plan()
+    params = dict(model.named_parameters())
+    fnames = fuse_param_names(opt)
+    fused = _FuseFunction.apply(model, fnames, fv, fi, *[params[n] for n in fnames])
+    ts = timestamps.detach().to(torch.float32)
+    tsd = ts - ts[:, :1]
+    obs = torch.cat([tsd[:, 1:, None].to(fused.device), fused], dim=-1)        # (plumbing: the concat's backward is a slice)
+    t_out = tsd[0, 1:].double().cpu().contiguous()
+    model.Pose_net.history = None
+    names = cde_param_names(opt)
+    return _CdeFunction.apply(model, names, t_out, obs, prev, *[params[n] for n in names])
+
+
 class PoseNetTrainer:
     """The reference's optimizer step for ``Pose_net`` on the device (scripts/train_model.py:48-95, utils/utils.py:115-130).
 
