@@ -273,12 +273,12 @@ size_t cde_bwd_workspace_floats(const CdeModel& m, int B, int n_out, int cap) {
   const size_t n = (size_t)B * m.H, Bp = (size_t)(B + 3) / 4 * 4, NL = (size_t)m.H * m.C;
   size_t f = 0;
   f += (size_t)cap * 8 * n;                         // tape: y + 7 stage derivatives per accepted step
-  f += ((size_t)cap * sizeof(CdeTapeMeta) + 3) / 4 + 2 * (size_t)n_out + 64;
+  f += ((size_t)cap * sizeof(CdeTapeMeta) + 15) / 16 * 4 + 2 * (((size_t)n_out + 3) / 4 * 4) + 64;   // (every buffer stays 16-byte aligned)
   f += 12 * n;                                      // gy, gk[7], lam_k0, v, zin, z0 copy
   f += (size_t)(m.n_hidden + 1) * n;                // hbuf
   f += (size_t)B * NL + NL * Bp + (size_t)m.H * Bp + Bp * m.H + 256 * Bp * (size_t)m.H;   // a_raw, g_aT, xT, gtmp, split partials
   f += (size_t)m.n_hidden * m.H * m.H + (size_t)m.C * m.H + (size_t)B * m.C;                // transposed weights, g_obs0
-  f += (size_t)B * n_out * m.H + (size_t)B * n_out * 128 * 2 + 4096;                        // g_sol, regressor scratch
+  f += 2 * (size_t)B * n_out * m.H + (size_t)B * n_out * 128 * 2 + 4096;                    // sol, g_sol, regressor scratch
   return f;
 }
 
@@ -294,9 +294,9 @@ int cde_backward(const CdeModel& m, const CdeWork& w, float* ws, const float* ob
   tp.cap = cap;
   tp.y = q; q += (size_t)cap * n;
   tp.k = q; q += (size_t)cap * 7 * n;
-  tp.meta = reinterpret_cast<CdeTapeMeta*>(q); q += ((size_t)cap * sizeof(CdeTapeMeta) + 3) / 4;
-  tp.out_x = q; q += n_out;
-  tp.out_step = reinterpret_cast<int*>(q); q += n_out;
+  tp.meta = reinterpret_cast<CdeTapeMeta*>(q); q += ((size_t)cap * sizeof(CdeTapeMeta) + 15) / 16 * 4;
+  tp.out_x = q; q += ((size_t)n_out + 3) / 4 * 4;
+  tp.out_step = reinterpret_cast<int*>(q); q += ((size_t)n_out + 3) / 4 * 4;
   tp.overflow = reinterpret_cast<int*>(q); q += 64;
   float* gy = q; q += n;
   float* gk = q; q += 7 * (size_t)n;
@@ -315,7 +315,7 @@ int cde_backward(const CdeModel& m, const CdeWork& w, float* ws, const float* ob
   float* initT = q; q += (size_t)C * H;      // [C][H]
   float* g_obs0 = q; q += (size_t)B * C;
   float* sol = q; q += (size_t)B * n_out * H;
-  float* g_sol = sol;                         // the regressor's backward overwrites the solution with its gradient
+  float* g_sol = q; q += (size_t)B * n_out * H;
   float* reg_ws = q; q += (size_t)B * n_out * 128 * 2;
 
   (void)hipMemsetAsync(tp.overflow, 0, sizeof(int), st);
