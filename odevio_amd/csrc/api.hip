@@ -1923,11 +1923,9 @@ static int fill_train_model(odevio_plan* p, TrainModel& m) {
   if (m.with_ode) {
     IntegTableau t;
     fill_tableau(c.ode_solver, t);
-    if (!is_fixed_step(c.ode_solver)) {
-      if (!t.has_err)   // euler under torchode's controller: 1e-4 steps to the end (thousands per interval)
-        return fail(ODEVIO_ERR_UNSUPPORTED, "backward: the euler solver (dt0-sized steps without an error estimate) is not supported");
-      m.adaptive = 1;
-    }
+    // (euler under torchode's controller takes dt0-sized steps to the end of every interval - a thousand per 0.1 s at the reference's
+    // dt0 = 1e-4: replayed like any other logged step sequence, at the cost of that many launches)
+    if (!is_fixed_step(c.ode_solver)) m.adaptive = 1;
     // FSAL pairs: the last stage only feeds the error estimate (b_last = 0); the replay does not need it
     m.stages = t.fsal ? t.stages - 1 : t.stages;
     m.jmax = m.adaptive ? 0 : c.ode_substeps;   // adaptive: set by the caller from the forward's step log
@@ -1939,7 +1937,10 @@ static int fill_train_model(odevio_plan* p, TrainModel& m) {
   return 0;
 }
 
-#define TRAIN_DTLOG_CAP 48   // accepted steps per row and interval the log holds (the reference's tolerances take 4-6)
+// accepted steps per row and interval the log holds: the reference's tolerances take 4 - 6; a log that overflows is retried once with
+// 8 x the room; euler (no error estimate: every dt0 step is accepted) is sized from the longest interval the caller could mean
+#define TRAIN_DTLOG_CAP 64
+#define TRAIN_DTLOG_CAP_MAX 16384
 
 extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
                                   const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
@@ -1986,19 +1987,30 @@ extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const floa
     // the forward once more on the persistent kernel, this time logging every accepted step size per row and interval;
     // the host needs ONE number from it (the largest step count, which sizes the replay)
     const int R = m.L * B;
-    const size_t n_log = (size_t)R * P * TRAIN_DTLOG_CAP, n_cnt = (size_t)R * P;
-    if ((rc = ensure(p->train_log, n_log + n_cnt + (size_t)R * F)) || (rc = ensure(p->out_seq, (size_t)B * P * F))) return rc;
-    float* dtlog = p->train_log.p;
-    int* dtcnt = reinterpret_cast<int*>(p->train_log.p + n_log);
-    float* hT_tmp = p->train_log.p + n_log + n_cnt;
-    HIPCHK(hipMemsetAsync(dtcnt, 0, n_cnt * sizeof(int), st));
-    if ((rc = run_sequence(p, fused, ts, hc_in, B, P, p->out_seq.p, hT_tmp, nullptr, st, dtlog, dtcnt, TRAIN_DTLOG_CAP))) return rc;
-    std::vector<int> cnt(n_cnt);
-    HIPCHK(hipMemcpyAsync(cnt.data(), dtcnt, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if ((rc = odevio_check(p, stream))) return rc;     // a step budget / log overflow of that forward
-    m.jmax = std::max(1, *std::max_element(cnt.begin(), cnt.end()));
-    m.dtlog = dtlog; m.dtcnt = dtcnt; m.dtlog_cap = TRAIN_DTLOG_CAP;
+    IntegTableau tb;
+    fill_tableau(p->cfg.ode_solver, tb);
+    int cap = tb.has_err ? TRAIN_DTLOG_CAP : std::min(TRAIN_DTLOG_CAP_MAX, std::max(TRAIN_DTLOG_CAP, p->cfg.max_steps));
+    for (int attempt = 0;; ++attempt) {
+      const size_t n_log = (size_t)R * P * cap, n_cnt = (size_t)R * P;
+      if ((rc = ensure(p->train_log, n_log + n_cnt + (size_t)R * F)) || (rc = ensure(p->out_seq, (size_t)B * P * F))) return rc;
+      float* dtlog = p->train_log.p;
+      int* dtcnt = reinterpret_cast<int*>(p->train_log.p + n_log);
+      float* hT_tmp = p->train_log.p + n_log + n_cnt;
+      HIPCHK(hipMemsetAsync(dtcnt, 0, n_cnt * sizeof(int), st));
+      if ((rc = run_sequence(p, fused, ts, hc_in, B, P, p->out_seq.p, hT_tmp, nullptr, st, dtlog, dtcnt, cap))) return rc;
+      std::vector<int> cnt(n_cnt);
+      HIPCHK(hipMemcpyAsync(cnt.data(), dtcnt, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      rc = odevio_check(p, stream);     // a step budget / log overflow of that forward
+      if (rc == ODEVIO_ERR_MAX_STEPS && attempt == 0 && cap < TRAIN_DTLOG_CAP_MAX) {
+        cap = std::min(TRAIN_DTLOG_CAP_MAX, cap * 8);   // the forward itself succeeded when it produced these inputs: the LOG was too short
+        continue;
+      }
+      if (rc) return rc;
+      m.jmax = std::max(1, *std::max_element(cnt.begin(), cnt.end()));
+      m.dtlog = dtlog; m.dtcnt = dtcnt; m.dtlog_cap = cap;
+      break;
+    }
   }
   if ((rc = ensure(p->train_ws, train_workspace_floats(m, B, P)))) return rc;
   rc = train_ode_rnn_bwd(m, p->train_ws.p, fused, ts, hc_in, B, P, grad_poses, grad_hT, grad_fused, grad_hc, g, st);

@@ -111,15 +111,43 @@ def test_adaptive_solver_backward_replays_the_accepted_steps(cfg):
     assert not bad, f"gradients off by more than {GTOL}: {bad}"
 
 
-def test_backward_refuses_what_is_not_built():
+def test_euler_backward_replays_every_dt0_step():
+    """euler under torchode's controller (PoseODERNN.py:125-137) has no error estimate: every dt0 = 1e-4 step is accepted until the
+    interval's end (the last one clipped) - a thousand steps per 0.1 s.  The backward replays them like any logged step sequence; short
+    intervals (20 - 45 steps each, different per row) keep the test quick.  Also: a step log that overflows its first size is retried."""
     opt = default_opt(img_h=64, img_w=128, ode_solver="euler")
-    model, _ = make_model(opt, seed=72)
-    fv, fi = torch.randn(2, 3, 512).cuda().requires_grad_(True), torch.randn(2, 3, 256).cuda()
-    ts = torch.tensor([[0.0, 0.001, 0.002, 0.003]]).repeat(2, 1)      # euler takes 1e-4 steps: keep the forward short
-    poses, _ = train.pose_net(model, fv, fi, ts.cuda())
-    with pytest.raises(ValueError, match="euler"):
-        poses.sum().backward()
-
+    model, sd = make_model(opt, seed=72)
+    B, P, L, F = 2, 3, 2, 768
+    g = torch.Generator().manual_seed(7)
+    fv, fi = torch.randn(B, P, 512, generator=g), torch.randn(B, P, 256, generator=g)
+    ts = torch.tensor([[0.0, 0.0021, 0.0052, 0.0097], [1.0, 1.0034, 1.0061, 1.0083]])
+    hc = torch.randn(L, B, F, generator=g) * 0.3
+    gts = torch.randn(B, P, 6, generator=g) * torch.tensor([0.01, 0.02, 0.01, 0.05, 0.05, 1.0])
+    names = train.pose_param_names(opt)
+    ref = _oracle_grads(sd, fv, fi, ts, hc, gts, opt, names, dtype=torch.float32)
+    fv_d, fi_d, hc_d = fv.cuda().requires_grad_(True), fi.cuda().requires_grad_(True), hc.cuda().requires_grad_(True)
+    poses, _ = train.pose_net(model, fv_d, fi_d, ts.cuda(), hc_d)
+    train.pose_loss(poses, gts.cuda()).backward()
+    model.check()
+    assert oc.rel_err(poses, ref["poses"]) < 1e-4
+    errs = {"fv": oc.rel_err(fv_d.grad, ref["fv"]), "fi": oc.rel_err(fi_d.grad, ref["fi"]), "hc": oc.rel_err(hc_d.grad, ref["hc"])}
+    params = dict(model.named_parameters())
+    for n in names:
+        errs[n] = oc.rel_err(params[n].grad, ref[n])
+    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v < GTOL}
+    assert not bad, f"gradients off by more than {GTOL}: {bad}"
+    # an interval of 0.0097 s = 97 accepted steps > the adaptive solvers' first log size (64): heun with a tight tolerance overflows it
+    opt2 = default_opt(img_h=64, img_w=128, ode_solver="heun")
+    opt2.ode_rtol, opt2.ode_atol = 2e-6, 1e-8
+    m2, _ = make_model(opt2, seed=72)
+    fv2 = fv.cuda().requires_grad_(True)
+    ts2 = torch.tensor([[0.0, 0.3, 0.7, 1.0], [0.0, 0.2, 0.5, 0.9]])
+    p2, _, stats = m2.pose_net(fv.cuda(), fi.cuda(), ts2.cuda(), None, return_stats=True)
+    assert int(stats[:, 1].max()) > 3 * 64, stats                       # more accepted steps per interval than the first log holds
+    p3, _ = train.pose_net(m2, fv2, fi.cuda(), ts2.cuda())
+    p3.sum().backward()
+    m2.check()
+    assert torch.isfinite(fv2.grad).all() and float(fv2.grad.abs().max()) > 0
 
 
 def test_pose_loss_matches_the_reference_formula():
