@@ -1937,8 +1937,8 @@ static int fill_train_model(odevio_plan* p, TrainModel& m) {
   return 0;
 }
 
-// accepted steps per row and interval the log holds: the reference's tolerances take 4 - 6; a log that overflows is retried once with
-// 8 x the room; euler (no error estimate: every dt0 step is accepted) is sized from the longest interval the caller could mean
+// accepted steps per row and interval the log holds: the reference's tolerances take 4 - 6; a log that overflows is retried with
+// 8 x the room (up to TRAIN_DTLOG_CAP_MAX); euler (no error estimate: every dt0 step is accepted) is sized from the longest interval the caller could mean
 #define TRAIN_DTLOG_CAP 64
 #define TRAIN_DTLOG_CAP_MAX 16384
 
@@ -2002,7 +2002,7 @@ extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const floa
       HIPCHK(hipMemcpyAsync(cnt.data(), dtcnt, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       rc = odevio_check(p, stream);     // a step budget / log overflow of that forward
-      if (rc == ODEVIO_ERR_MAX_STEPS && attempt == 0 && cap < TRAIN_DTLOG_CAP_MAX) {
+      if (rc == ODEVIO_ERR_MAX_STEPS && attempt < 3 && cap < TRAIN_DTLOG_CAP_MAX) {
         cap = std::min(TRAIN_DTLOG_CAP_MAX, cap * 8);   // the forward itself succeeded when it produced these inputs: the LOG was too short
         continue;
       }
