@@ -1908,15 +1908,15 @@ extern "C" int odevio_cde_bwd(odevio_plan* p, const float* obs, int32_t B, int32
 static int fill_train_model(odevio_plan* p, TrainModel& m) {
   const odevio_config& c = p->cfg;
   if (c.model_type == ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "backward: the Neural-CDE path has no backward yet");
-  if (p->padded || p->F % 16 || (c.model_type == ODEVIO_MODEL_ODE_RNN && c.ode_hidden_dim % 16))
-    return fail(ODEVIO_ERR_UNSUPPORTED, "backward: v_f_len+i_f_len (%d) and ode_hidden_dim (%d) must be multiples of 32 (the forward pads other widths)",
-                p->F, c.ode_hidden_dim);
+  // (the tape runs on plain GEMMs over the REAL widths - only the persistent forward kernel pads them - and needs whole float4 rows)
+  if (p->F % 4 || (c.model_type == ODEVIO_MODEL_ODE_RNN && c.ode_hidden_dim % 4))
+    return fail(ODEVIO_ERR_UNSUPPORTED, "backward: v_f_len+i_f_len (%d) and ode_hidden_dim (%d) must be multiples of 4", p->F, c.ode_hidden_dim);
   m = p->train;
   m.gru = c.rnn_type == ODEVIO_RNN_GRU;
   m.F = p->F; m.H = c.ode_hidden_dim; m.L = c.rnn_num_layers; m.act = c.ode_activation;
   m.with_ode = c.model_type == ODEVIO_MODEL_ODE_RNN;
   m.nlin = m.with_ode ? p->nlin : 0;
-  for (int l = 0; l <= p->nlin; ++l) m.dims[l] = p->dims[l];
+  for (int l = 0; l <= p->nlin; ++l) m.dims[l] = p->dims_real[l];
   for (int l = 0; l < p->nlin; ++l) m.ode_b[l] = p->ode_b[l];
   m.reg_w0 = p->reg_w0; m.reg_b0 = p->reg_b0; m.reg_w2 = p->reg_w2; m.reg_b2 = p->reg_b2;
   m.stages = 1; m.jmax = 1; m.adaptive = 0; m.dtlog = nullptr; m.dtcnt = nullptr; m.dtlog_cap = 0;

@@ -448,7 +448,11 @@ class PoseNetTrainer:
                 _lib.check(lib.odevio_sgd_step(p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), p.numel(), lr, 0.9, 0.0, self.steps,
                                                self.norm_coef.data_ptr(), stream))
         # the kernels read their own layouts of these parameters (column shards, transposes): refresh them in place
-        _lib.check(lib.odevio_plan_update(model._plan, _tensor_array(self.names, [p.detach() for p in self.params]), len(self.params), stream))
+        rc = lib.odevio_plan_update(model._plan, _tensor_array(self.names, [p.detach() for p in self.params]), len(self.params), stream)
+        if rc == _lib.ERR_UNSUPPORTED:      # widths the integrator pads (F = 400, H = 200): no in-place re-layout - rebuild the plan at the next forward
+            model._plan_sig = None
+            return True
+        _lib.check(rc)
         model._plan_sig = model._signature()
         return True
 

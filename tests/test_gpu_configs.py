@@ -296,10 +296,21 @@ def test_ode_rnn_widths_that_are_not_multiples_of_32(dev, cfg):
     r3, rh3 = oc.deepvio_forward(sd, img, imu, ts3, None, opt)
     assert_close(p3, r3, what="poses (DeepVIO.forward)")
     assert_close(h3, rh3, what="h_T (DeepVIO.forward)")
-    if opt.ode_solver == "rk4":
-        from odevio_amd import train
-        with pytest.raises(ValueError):                   # the backward says what it cannot do instead of computing on padded shapes
-            train.pose_net(model, fv.cuda().requires_grad_(), fi.cuda(), ts.cuda())[0].sum().backward()
+    # the backward runs on the caller's widths too (its tape is plain GEMMs; only the persistent forward kernel pads)
+    from odevio_amd import train
+    fv_d = fv.cuda().requires_grad_(True)
+    pg, _ = train.pose_net(model, fv_d, fi.cuda(), ts.cuda())
+    wgt = torch.randn(pg.shape, generator=g)
+    (pg * wgt.cuda()).sum().backward()
+    model.check()
+    leaves = {k: (v.clone().requires_grad_(k.startswith("Pose_net.")) if v.is_floating_point() else v) for k, v in sd.items()}
+    fv_r = fv.clone().requires_grad_(True)
+    pr, _ = oc.pose_ode_rnn(leaves, fv_r, fi, ts, None, opt, detach_controller=True)
+    (pr * wgt).sum().backward()
+    assert oc.rel_err(fv_d.grad, fv_r.grad) < 2e-3
+    now = dict(model.named_parameters())
+    for n in ("Pose_net.ode_func.net.0.weight", "Pose_net.ode_func.net.2.bias", "Pose_net.rnn.weight_hh_l0", "Pose_net.regressor.0.weight"):
+        assert oc.rel_err(now[n].grad, leaves[n].grad) < 2e-3, n
 
 
 def test_hard_fusion_on_the_cde_path_and_its_random_stream_survives_a_reload(dev):
