@@ -296,6 +296,8 @@ def test_ode_rnn_widths_that_are_not_multiples_of_32(dev, cfg):
     r3, rh3 = oc.deepvio_forward(sd, img, imu, ts3, None, opt)
     assert_close(p3, r3, what="poses (DeepVIO.forward)")
     assert_close(h3, rh3, what="h_T (DeepVIO.forward)")
+    if opt.ode_solver == "dopri5":
+        return                                 # (the backward below is exercised by the other two cases; dopri5 + GRU through the oracle is slow)
     # the backward runs on the caller's widths too (its tape is plain GEMMs; only the persistent forward kernel pads)
     from odevio_amd import train
     fv_d = fv.cuda().requires_grad_(True)
