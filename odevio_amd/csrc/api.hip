@@ -108,7 +108,11 @@ struct odevio_plan {
   // image-encoder backward (enc_bwd.hip): the flipped / transposed filters of the input-gradient convolutions, what a train-mode
   // forward with keep = 1 leaves behind (per block the bare convolution z and the block's output a, both P2; the batch statistics),
   // and scratch
-  float* conv_wT[9] = {};                  // [Cin][kh][kw][Cout], taps reversed (blocks 1..8)
+  float* conv_wT[9] = {};                  // [Cin][kh][kw][Cout], taps reversed (blocks 1..8): fp32-input MFMA form (ODEVIO_ENC_BWD_IGEMM)
+  void* conv_wTs[9] = {};                  // the same filters as two fp16 pieces for conv_f16x2_kernel: [Cin][K-tile][2][32]
+  size_t conv_wTs_bytes[9] = {};
+  float conv_wT_inv_prescale[9] = {};
+  float* enc_dscale = nullptr;             // [1024] epilogue scale of the current input-gradient convolution + one word for max|D|
   DevBuf enc_z[9], enc_a[9];
   float *enc_mean[9] = {}, *enc_invstd[9] = {};
   int enc_B = 0, enc_S = 0;                // shape of the kept forward (0: none)
@@ -214,7 +218,7 @@ static int ensure(DevBuf& b, size_t n) {
 static size_t extent_of(const odevio_plan* p, const void* ptr, size_t fallback) {
   const DevBuf* bufs[] = {&p->actA, &p->actB, &p->pack_tmp, &p->partial, &p->partial_side, &p->ingest, &p->fcat, &p->fused, &p->out_seq,
                           &p->enc_z[0], &p->enc_z[1], &p->enc_z[2], &p->enc_z[3], &p->enc_z[4], &p->enc_z[5], &p->enc_z[6], &p->enc_z[7], &p->enc_z[8],
-                          &p->enc_a[0], &p->enc_a[1], &p->enc_a[2], &p->enc_a[3], &p->enc_a[4], &p->enc_a[5], &p->enc_a[6], &p->enc_a[7], &p->enc_a[8]};
+                          &p->enc_Dd, &p->enc_a[0], &p->enc_a[1], &p->enc_a[2], &p->enc_a[3], &p->enc_a[4], &p->enc_a[5], &p->enc_a[6], &p->enc_a[7], &p->enc_a[8]};
   const uintptr_t a = (uintptr_t)ptr;
   for (const DevBuf* b : bufs) {
     const uintptr_t lo = (uintptr_t)b->p, hi = lo + b->n * sizeof(float);
@@ -666,6 +670,19 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
           for (int c = 0; c < cs.cin; ++c)
             for (int q = 0; q < kk; ++q) wT[((size_t)c * kk + (kk - 1 - q)) * cs.cout + n] = w[((size_t)n * cs.cin + c) * kk + q];
         TRY(upload(p, &p->conv_wT[i], wT, st));
+        // [Cin][Cout][taps reversed] -> pieces, K-tile = (group of Cout, tap)
+        std::vector<float> wr(w.size());
+        for (int n = 0; n < cs.cout; ++n)
+          for (int c = 0; c < cs.cin; ++c)
+            for (int q = 0; q < kk; ++q) wr[((size_t)c * cs.cout + n) * kk + (kk - 1 - q)] = w[((size_t)n * cs.cin + c) * kk + q];
+        std::vector<uint16_t> wts;
+        const float ps = split_conv_weights(wr, cs.cin, cs.cout, kk, wts);
+        p->conv_wT_inv_prescale[i] = 1.0f / ps;
+        p->conv_wTs_bytes[i] = wts.size() * sizeof(uint16_t);
+        wts.resize(wts.size() + ODEVIO_ZERO_PAGE_BYTES / sizeof(uint16_t), 0);
+        TRY(dev_alloc(p, &p->conv_wTs[i], wts.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpyAsync(p->conv_wTs[i], wts.data(), wts.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
       }
     }
     TRY(upload(p, &p->conv_scale[i], sc, st));
@@ -812,6 +829,8 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
     TRY(upload(p, &p->zero_vec, z, st));
     TRY(upload(p, &p->bn_scale, z, st));
     TRY(upload(p, &p->bn_shift, z, st));
+    std::vector<float> z2(1024 + 16, 0.f);
+    TRY(upload(p, &p->enc_dscale, z2, st));
   }
   // ---- exchange buffers + status
   p->xstride = 8 * INTEG_KMAX;
@@ -1257,7 +1276,7 @@ static int image_encoder_bwd(odevio_plan* p, const float* img, int B, int S, con
   for (int i = 0; i < 9; ++i) {
     const ConvSpec& cs = kConvs[i];
     n_act = std::max(n_act, (size_t)P * p->conv_h[i + 1] * p->conv_w_sp[i + 1] * cs.cout);
-    if (i > 0 && cs.stride > 1) n_dil = std::max(n_dil, (size_t)P * p->conv_h[i] * p->conv_w_sp[i] * cs.cout);
+    if (i > 0) n_dil = std::max(n_dil, (size_t)P * p->conv_h[i] * p->conv_w_sp[i] * cs.cout);   // (dilated to the input's size; stride 1: the same size)
     const int cin_k = i == 0 ? 8 : cs.cin;
     const int M = P * p->conv_h[i + 1] * p->conv_w_sp[i + 1];
     n_part = std::max(n_part, enc_wgrad_partial_floats(cs.cout, cin_k, cs.k * cs.k, enc_wgrad_pick_splits(M, cs.cout, cin_k, cs.k * cs.k)));
@@ -1319,6 +1338,40 @@ static int image_encoder_bwd(odevio_plan* p, const float* img, int B, int S, con
     if (cs.stride > 1) {
       Hd = Hi + 2 * pad - cs.k + 1;
       Wd = Wi + 2 * pad - cs.k + 1;
+    }
+    static const bool igemm = getenv("ODEVIO_ENC_BWD_IGEMM") != nullptr;   // diagnostic: the fp32-input MFMA form (4 x slower)
+    if (!igemm) {
+      // the forward's fp16x2 kernel: D scaled by a per-tensor power of two into the two-piece layout (zero-dilated in the same pass), the
+      // tap-reversed filter as pieces, an identity epilogue that divides both factors back out, fp32 output
+      unsigned* amax = reinterpret_cast<unsigned*>(p->enc_dscale + 1024);
+      enc_pack_dilate(D, p->enc_Dd.p, P, Ho, Wo, Hd, Wd, cs.cout, cs.stride, amax, p->enc_dscale, cs.cin, p->conv_wT_inv_prescale[i], st);
+      ConvSplitArgs a{};
+      a.in = p->enc_Dd.p; a.w = p->conv_wTs[i]; a.zeros = p->zero_page; a.out = gA; a.status = p->status;
+      a.scale = p->enc_dscale; a.shift = p->zero_vec;
+      a.N = P; a.Hi = Hd; a.Wi = Wd; a.Cin = cs.cout; a.Ho = Hi; a.Wo = Wi; a.Cout = cs.cin; a.KH = a.KW = cs.k; a.stride = 1; a.pad = cs.k - 1 - pad;
+      a.M = P * Hi * Wi; a.slope = 1.0f; a.out_split = 0; a.ld_out = cs.cin; a.terms = 3;
+      a.in_bytes = extent_of(p, a.in, (size_t)P * Hd * Wd * cs.cout * sizeof(float));
+      a.w_bytes = p->conv_wTs_bytes[i];
+      set_off32(p, a, a.in);
+      a.out_bytes = extent_of(p, gA, (size_t)a.M * a.Cout * sizeof(float));
+      const int nkt = cs.k * cs.k * cs.cout / 32;
+      const ConvPlanF plan = plan_f16x2(16 + i, a.M, a.Cout, nkt, p->n_cu, a.off32 != 0);
+      for (int ph = 0; ph < plan.n; ++ph) {
+        const ConvPhase& f = plan.ph[ph];
+        a.wide = f.wide; a.bm = f.bm; a.m_begin = f.m_begin; a.m_end = f.m_end;
+        a.splitk = f.splitk;
+        a.ktiles_per_split = (nkt + a.splitk - 1) / a.splitk;
+        a.splitk = (nkt + a.ktiles_per_split - 1) / a.ktiles_per_split;
+        if (a.splitk > 1) {
+          if ((rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout))) return rc;
+          a.partial = p->partial.p;
+          a.partial_bytes = p->partial.n * sizeof(float);
+        }
+        HIPCHK(launch_conv_f16x2(a, st));
+      }
+      continue;
+    }
+    if (cs.stride > 1) {
       enc_dilate(D, p->enc_Dd.p, P, Ho, Wo, Hd, Wd, cs.cout, cs.stride, st);
       din = p->enc_Dd.p;
     }

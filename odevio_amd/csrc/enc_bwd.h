@@ -38,6 +38,11 @@ hipError_t enc_wgrad(const WgradArgs& a, hipStream_t st);
 // D [N][Ho][Wo][C] -> Dd [N][Hd][Wd][C] with Dd[n][s ho][s wo] = D[n][ho][wo] and zeros elsewhere (the input of the stride-1
 // convolution that IS the input gradient of a stride-s convolution)
 void enc_dilate(const float* D, float* Dd, int N, int Ho, int Wo, int Hd, int Wd, int C, int stride, hipStream_t st);
+// The same dilation straight into the forward kernel's two-fp16-piece layout, scaled by a per-tensor power of two 2^e chosen from
+// max|D| on the device (largest element in [2^10, 2^11)); scale[0 .. n_scale) <- inv_prescale * 2^-e = the epilogue scale that undoes
+// both the filter's pre-scale and e.  amax: one device word of scratch.
+void enc_pack_dilate(const float* D, void* out, int N, int Ho, int Wo, int Hd, int Wd, int C, int stride, unsigned* amax, float* scale, int n_scale,
+                     float inv_prescale, hipStream_t st);
 // img [B][S][3][H][W] -> frame pairs as NHWC with 8 channel slots [B*(S-1)][H][W][8] (conv1's input for the weight gradient; slots 6, 7 zero)
 void enc_pairs_nhwc8(const float* img, float* out, int B, int S, int H, int W, hipStream_t st);
 // visual_head weight gradient from the kernels' (H, W, C) column order back to the reference's flatten order (C, H, W): out[n][c][s] = in[n][s][c]

@@ -233,6 +233,56 @@ __global__ void dilate_kernel(const float* __restrict__ D, float* __restrict__ D
     *reinterpret_cast<f32x4*>(Dd + i * 4) = v;
   }
 }
+// ---- input gradient on the forward's fp16x2 kernel: D (fp32) -> P2 pieces of D * 2^e, zero-dilated for a stride-s convolution.
+// e is chosen per tensor from max|D| (device word `amax`, float bits) so that the largest element lands in [2^10, 2^11): gradients are
+// many orders of magnitude smaller than activations and would otherwise sit in fp16's subnormals.  The factor is divided back out in the
+// convolution's epilogue scale (enc_fill_scale), exactly (a power of two).
+__global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ amax) {
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);     // |x| bit patterns order like the values (NaN / inf on top)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(amax, m);
+}
+__device__ __forceinline__ int grad_exponent(unsigned amax_bits) {
+  if (amax_bits == 0 || amax_bits >= 0x7f800000u) return 0;
+  int ex;
+  (void)frexpf(__uint_as_float(amax_bits), &ex);          // |max| = f * 2^ex, f in [0.5, 1)
+  return max(-100, min(100, 11 - ex));                     // |max| * 2^e in [2^10, 2^11)
+}
+__global__ void pack_dilate_kernel(const float* __restrict__ D, unsigned char* __restrict__ out, int N, int Ho, int Wo, int Hd, int Wd, int C, int stride,
+                                   const unsigned* __restrict__ amax) {
+  const float sc = ldexpf(1.0f, grad_exponent(*amax));
+  const int Q = C >> 2;
+  const size_t total4 = (size_t)N * Hd * Wd * Q;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = 4 * (int)(i % Q);
+    const size_t pix = i / Q;
+    size_t p = pix;
+    const int wd = (int)(p % Wd);
+    p /= Wd;
+    const int hd = (int)(p % Hd);
+    const int n = (int)(p / Hd);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (hd % stride == 0 && wd % stride == 0 && hd / stride < Ho && wd / stride < Wo)
+      v = *reinterpret_cast<const f32x4*>(D + (((size_t)n * Ho + hd / stride) * Wo + wd / stride) * C + c) * sc;
+    h16x4_t h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (_Float16)v[e];
+      l[e] = (_Float16)(v[e] - (float)h[e]);
+    }
+    unsigned char* q = out + (pix * (size_t)(C >> 5) + (size_t)(c >> 5)) * 128 + (size_t)(c & 31) * 2;
+    *reinterpret_cast<h16x4_t*>(q) = h;
+    *reinterpret_cast<h16x4_t*>(q + 64) = l;
+  }
+}
+__global__ void fill_scale_kernel(float* __restrict__ sc, int n, float inv_prescale, const unsigned* __restrict__ amax) {
+  const float v = ldexpf(inv_prescale, -grad_exponent(*amax));
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) sc[i] = v;
+}
+
 __global__ void pairs_nhwc8_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int S, int H, int W) {
   const size_t HW = (size_t)H * W;
   const size_t total = (size_t)B * (S - 1) * HW;
@@ -314,6 +364,15 @@ hipError_t enc_wgrad(const WgradArgs& a_in, hipStream_t st) {
 
 void enc_dilate(const float* D, float* Dd, int N, int Ho, int Wo, int Hd, int Wd, int C, int stride, hipStream_t st) {
   hipLaunchKernelGGL(dilate_kernel, dim3(ew_blocks((size_t)N * Hd * Wd * (C >> 2))), dim3(256), 0, st, D, Dd, N, Ho, Wo, Hd, Wd, C, stride);
+}
+void enc_pack_dilate(const float* D, void* out, int N, int Ho, int Wo, int Hd, int Wd, int C, int stride, unsigned* amax, float* scale, int n_scale,
+                     float inv_prescale, hipStream_t st) {
+  (void)hipMemsetAsync(amax, 0, sizeof(unsigned), st);
+  const size_t n = (size_t)N * Ho * Wo * C;
+  hipLaunchKernelGGL(absmax_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, D, n, amax);
+  hipLaunchKernelGGL(pack_dilate_kernel, dim3(ew_blocks((size_t)N * Hd * Wd * (C >> 2))), dim3(256), 0, st, D, reinterpret_cast<unsigned char*>(out), N, Ho,
+                     Wo, Hd, Wd, C, stride, amax);
+  hipLaunchKernelGGL(fill_scale_kernel, dim3((n_scale + 255) / 256), dim3(256), 0, st, scale, n_scale, inv_prescale, amax);
 }
 void enc_pairs_nhwc8(const float* img, float* out, int B, int S, int H, int W, hipStream_t st) {
   hipLaunchKernelGGL(pairs_nhwc8_kernel, dim3(ew_blocks((size_t)B * (S - 1) * H * W)), dim3(256), 0, st, img, out, B, S, H, W);
