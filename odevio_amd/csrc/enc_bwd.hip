@@ -142,38 +142,60 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
   const float* xf = reinterpret_cast<const float*>(a.x);
   const int G = a.Cin >> 5;
+  const int chunk_begin = split * a.chunks_per_split;
   const int chunk_end = min((split + 1) * a.chunks_per_split, (a.M + WG_PX - 1) / WG_PX);
-  for (int ch = split * a.chunks_per_split; ch < chunk_end; ++ch) {
-    const int m0 = ch * WG_PX;
+  const bool co_ok = co0 + lcol < a.Cout, ci_ok = ci0 + lcol < a.Cin;
+  // (image, row, column) of this thread's four loader rows, advanced by carries from chunk to chunk (two divisions per row ONCE, not per chunk:
+  // the address arithmetic of the first version cost as much issue time as the MFMAs)
+  int pn[4], pho[4], pwo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = chunk_begin * WG_PX + lrow + 16 * j;
+    pn[j] = m / HoWo;
+    const int rem = m - pn[j] * HoWo;
+    pho[j] = rem / a.Wo;
+    pwo[j] = rem - pho[j] * a.Wo;
+  }
+  f32x4 dv[4], xv[4];
+  auto fetch = [&](int ch) __attribute__((always_inline)) {   // chunk ch -> registers (the loads stay in flight under the previous chunk's MFMAs)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = lrow + 16 * j;
-      const int m = m0 + row;
-      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+      const int m = ch * WG_PX + lrow + 16 * j;
+      dv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (m < a.M) {
-        const int co = co0 + lcol;
-        if (co < a.Cout) dv = *reinterpret_cast<const f32x4*>(a.D + (size_t)m * a.Cout + co);   // (Cout % 4 == 0)
-        const int n = m / HoWo;
-        const int rem = m - n * HoWo;
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        const int hi = ho * a.stride + kh - a.pad, wi = wo * a.stride + kw - a.pad;
-        const int ci = ci0 + lcol;
-        if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi && ci < a.Cin) {
-          const size_t pi = ((size_t)n * a.Hi + hi) * a.Wi + wi;
+        if (co_ok) dv[j] = *reinterpret_cast<const f32x4*>(a.D + (size_t)m * a.Cout + co0 + lcol);   // (Cout % 4 == 0)
+        const int hi = pho[j] * a.stride + kh - a.pad, wi = pwo[j] * a.stride + kw - a.pad;
+        if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi && ci_ok) {
+          const size_t pi = ((size_t)pn[j] * a.Hi + hi) * a.Wi + wi;
+          const int ci = ci0 + lcol;
           if (a.x_f32) {
-            xv = *reinterpret_cast<const f32x4*>(xf + pi * a.ldx + ci);
+            xv[j] = *reinterpret_cast<const f32x4*>(xf + pi * a.ldx + ci);
           } else {
             const unsigned char* p = xb + (pi * (size_t)G + (size_t)(ci >> 5)) * 128 + (size_t)(ci & 31) * 2;
             const h16x4_t h = *reinterpret_cast<const h16x4_t*>(p), l = *reinterpret_cast<const h16x4_t*>(p + 64);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] = (float)h[e] + (float)l[e];
+            for (int e = 0; e < 4; ++e) xv[j][e] = (float)h[e] + (float)l[e];
           }
         }
       }
-      *reinterpret_cast<f32x4*>(&Dt[row * WG_LD + lcol]) = dv;
-      *reinterpret_cast<f32x4*>(&Xt[row * WG_LD + lcol]) = xv;
+      pwo[j] += WG_PX;                                  // this row's pixel in the NEXT chunk
+      while (pwo[j] >= a.Wo) {
+        pwo[j] -= a.Wo;
+        if (++pho[j] == a.Ho) { pho[j] = 0; ++pn[j]; }
+      }
+    }
+  };
+  if (chunk_begin < chunk_end) fetch(chunk_begin);
+  for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+    __syncthreads();                                    // every wave is done reading the previous chunk
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<f32x4*>(&Dt[(lrow + 16 * j) * WG_LD + lcol]) = dv[j];
+      *reinterpret_cast<f32x4*>(&Xt[(lrow + 16 * j) * WG_LD + lcol]) = xv[j];
     }
     __syncthreads();
+    if (ch + 1 < chunk_end) fetch(ch + 1);
 #pragma unroll 4
     for (int kk = 0; kk < WG_PX / 4; ++kk) {
       const int prow = (4 * kk + q) * WG_LD;
@@ -187,7 +209,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
   }
   // C/D map of the 16x16x4 MFMA: lane (r, q), register e = [row 4 q + e][column r] = [co][ci]
   float* slab = a.partial + ((size_t)split * taps + tap) * a.Cout * a.Cin;
