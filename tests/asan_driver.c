@@ -52,6 +52,14 @@ int main(void) {
   EXPECT(odevio_rng_state(NULL, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_debug_gumbel(0, 0, 0, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_set_seed(NULL, 1) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_set_rng_state(NULL, 1, 2) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_image_encoder_fwd_train(NULL, x, 1, 2, x, 512, NULL, 0, 0, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_imu_encoder_fwd_train(NULL, x, 1, 11, 0.0f, NULL, 0, x, 256, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_imu_encoder_bwd_train(NULL, x, 1, 11, 0.0f, 0, 0, x, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_image_encoder_bwd(NULL, x, 1, 2, x, 512, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_cde_bwd(NULL, x, 1, 2, NULL, 1, NULL, x, NULL, x, NULL, NULL, 0, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
+  EXPECT(odevio_debug_dropout(0, 0, 1.5f, 4, x, NULL) == ODEVIO_ERR_BAD_ARG);     /* p must be < 1 */
+  EXPECT(odevio_sgd_step(x, x, NULL, 4, 1e-4f, 0.9f, 0.0f, 1, NULL, NULL) == ODEVIO_ERR_BAD_ARG);   /* momentum needs its buffer */
   EXPECT(odevio_resize_u8(NULL, 1, 4, 4, NULL, 2, 2, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   odevio_plan_destroy(NULL);
   /* resize tables: KITTI width and height, an upscale, a degenerate 1-pixel axis; capacity checked */
