@@ -176,14 +176,29 @@ int odevio_cde_bwd(odevio_plan* plan, const float* obs, int32_t B, int32_t L, co
  * outputs grad_fused [B,P,F] (or NULL), grad_hc [L,B,F] (or NULL; needs hc_in) and the weight gradients listed in
  * `grads`: name = the reference state_dict key (Pose_net.ode_func.net.{0,2,..}.{weight,bias},
  * Pose_net.rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l{k}, Pose_net.regressor.{0,2}.{weight,bias}), data = DEVICE pointer
- * the gradient is WRITTEN to (same shape as the parameter), numel checked.  The forward is recomputed inside (nothing is
- * kept from odevio_ode_rnn_fwd).  Fixed-step solvers (rk4, rk4_classic, any ode_substeps) are differentiated as they
- * stand; for the adaptive ones (dopri5, tsit5, heun) the forward runs once more with a log of every ACCEPTED step
- * size per row and interval, and those steps are replayed with their sizes held constant (one host read of the largest
- * step count).  nn.RNN (tanh) and nn.GRU.  ODEVIO_ERR_UNSUPPORTED for the euler solver and the Neural-CDE path. */
+ * the gradient is WRITTEN to (same shape as the parameter), numel checked.  Nothing is kept from odevio_ode_rnn_fwd: the
+ * forward runs once more on the persistent kernel, logging per row and interval every ACCEPTED step (its size and the state it
+ * starts from) and the evolved state; from that log every stage of every step is rebuilt in one batch, then swept in reverse.
+ * Fixed-step solvers (rk4, rk4_classic, any ode_substeps) are differentiated as they stand; for the adaptive ones (dopri5,
+ * tsit5, heun, euler) the accepted steps are replayed with their sizes held constant (one host read: the largest step
+ * count).  nn.RNN (tanh) and nn.GRU.  ODEVIO_ERR_UNSUPPORTED for the Neural-CDE path (odevio_cde_bwd). */
 int odevio_ode_rnn_bwd(odevio_plan* plan, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
                        const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
                        const odevio_tensor* grads, int32_t n_grads, void* stream);
+/* The same pair with the log kept by the CALLER between forward and backward, so that a training step runs the persistent kernel
+ * once (what autograd's saved tensors are to `poses = model(...)` ... `loss.backward()`, scripts/train_model.py:69-78):
+ *   odevio_ode_rnn_tape_floats  -> *n_floats = size of the device buffer (fp32 elements) a taped forward of (B, P) fills; 0 for
+ *                                  plans without an ODE (use the plain pair);
+ *   odevio_ode_rnn_fwd_taped    = odevio_ode_rnn_fwd + the log written to `tape`;
+ *   odevio_ode_rnn_bwd_taped    = odevio_ode_rnn_bwd reading that log instead of running the forward again (same plan, same
+ *                                  inputs, weights unchanged in between).  A log that proved too short for an interval (more than 64
+ *                                  accepted steps) is rebuilt inside with more room, like the plain backward does. */
+int odevio_ode_rnn_tape_floats(const odevio_plan* plan, int32_t B, int32_t P, int64_t* n_floats);
+int odevio_ode_rnn_fwd_taped(odevio_plan* plan, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
+                             float* poses, float* h_T, float* tape, int64_t tape_floats, void* stream);
+int odevio_ode_rnn_bwd_taped(odevio_plan* plan, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
+                             const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
+                             const odevio_tensor* grads, int32_t n_grads, const float* tape, int64_t tape_floats, void* stream);
 /* The reference's training loss and its gradient (scripts/train_model.py:72-77): loss3 (device, 3 floats) =
  * {100 * angle_loss + translation_loss, angle_loss, translation_loss} with MSE over the first / last three pose columns of
  * n_rows = B*P rows; grad_poses [n_rows,6] = d loss3[0] / d poses, or NULL. */

@@ -29,6 +29,7 @@ SYMBOLS = [
     "odevio_rng_state", "odevio_debug_gumbel", "odevio_fuse_hard_bwd", "odevio_set_rng_state",
     "odevio_image_encoder_fwd_train", "odevio_imu_encoder_fwd_train", "odevio_imu_encoder_bwd_train", "odevio_debug_dropout",
     "odevio_sgd_step", "odevio_image_encoder_bwd", "odevio_cde_bwd",
+    "odevio_ode_rnn_tape_floats", "odevio_ode_rnn_fwd_taped", "odevio_ode_rnn_bwd_taped",
 ]
 
 
@@ -111,6 +112,9 @@ def load():
     lib.odevio_cde_last_ms.argtypes = [vp, fp]
     lib.odevio_cde_bwd.argtypes = [vp, fp, i32, i32, vp, i32, fp, fp, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp, vp]
     lib.odevio_ode_rnn_bwd.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]
+    lib.odevio_ode_rnn_tape_floats.argtypes = [vp, i32, i32, ctypes.POINTER(ctypes.c_int64)]
+    lib.odevio_ode_rnn_fwd_taped.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, fp, ctypes.c_int64, vp]
+    lib.odevio_ode_rnn_bwd_taped.argtypes = [vp, fp, fp, fp, i32, i32, fp, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, fp, ctypes.c_int64, vp]
     lib.odevio_pose_loss.argtypes = [fp, fp, i32, fp, fp, vp]
     f32 = ctypes.c_float
     lib.odevio_fuse_bwd.argtypes = [vp, fp, fp, i32, fp, fp, fp, ctypes.POINTER(OdevioTensor), i32, vp]

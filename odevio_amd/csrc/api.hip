@@ -1567,9 +1567,17 @@ static int launch_integ(odevio_plan* p, IntegArgs& a, int rt, size_t lds, hipStr
   return 0;
 }
 
+// The backward's log of a forward (integrator.h): where the persistent kernel writes it.  All null = no log.
+struct StepLog {
+  float* dtlog = nullptr;
+  int* dtcnt = nullptr;
+  float* ylog = nullptr;
+  float* yend = nullptr;
+  int cap = 0;
+};
+
 static int run_sequence(odevio_plan* p, const float* fused, const float* ts, const float* hc, int B, int P,
-                        float* out_seq, float* hT, int32_t* stats, hipStream_t st, float* dtlog = nullptr, int* dtcnt = nullptr,
-                        int dtlog_cap = 0) {
+                        float* out_seq, float* hT, int32_t* stats, hipStream_t st, const StepLog& log = StepLog()) {
   RoctxRange range("odevio: ODE + RNN (persistent integrator)");   // the reference's "ODE" and "RNN" ranges are one launch here
   const int L = p->cfg.rnn_num_layers;
   const int bpg_max = 8 / L;  // rows per group <= 8
@@ -1587,7 +1595,7 @@ static int run_sequence(odevio_plan* p, const float* fused, const float* ts, con
     a.B = B; a.P = P; a.b_begin = b0; a.b_end = b0 + nb;
     a.BPG = BPG; a.G = (nb + BPG - 1) / BPG; a.rows_per_group = R;
     a.fused = fused; a.ts = ts; a.ts_relative = hc ? 0 : 1; a.hc = hc; a.out_seq = out_seq; a.hT = hT; a.stats = stats;
-    a.dtlog = dtlog; a.dtcnt = dtcnt; a.dtlog_cap = dtlog_cap;
+    a.dtlog = log.dtlog; a.dtcnt = log.dtcnt; a.dtlog_cap = log.cap; a.ylog = log.ylog; a.yend = log.yend;
     if ((rc = launch_integ(p, a, rt, lds, st))) return rc;
   }
   return 0;
@@ -1828,11 +1836,11 @@ extern "C" int odevio_ode_steps(odevio_plan* p, const float* y, const float* t0,
 }
 
 static int ode_rnn_fwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
-                       float* poses, float* h_T, int32_t* stats, hipStream_t st) {
+                       float* poses, float* h_T, int32_t* stats, hipStream_t st, const StepLog& log = StepLog()) {
   int rc;
   if ((rc = ensure(p->out_seq, (size_t)B * P * p->F))) return rc;
   stage_mark(p, 4, st);
-  if ((rc = run_sequence(p, fused, ts, hc_in, B, P, p->out_seq.p, h_T, stats, st))) return rc;
+  if ((rc = run_sequence(p, fused, ts, hc_in, B, P, p->out_seq.p, h_T, stats, st, log))) return rc;
   stage_mark(p, 5, st);
   rc = regress(p, p->out_seq.p, B * P, poses, st);
   stage_mark(p, 6, st);
@@ -1972,7 +1980,7 @@ static int fill_train_model(odevio_plan* p, TrainModel& m) {
   for (int l = 0; l <= p->nlin; ++l) m.dims[l] = p->dims_real[l];
   for (int l = 0; l < p->nlin; ++l) m.ode_b[l] = p->ode_b[l];
   m.reg_w0 = p->reg_w0; m.reg_b0 = p->reg_b0; m.reg_w2 = p->reg_w2; m.reg_b2 = p->reg_b2;
-  m.stages = 1; m.jmax = 1; m.adaptive = 0; m.dtlog = nullptr; m.dtcnt = nullptr; m.dtlog_cap = 0;
+  m.stages = 1; m.jmax = 1; m.adaptive = 0; m.dtlog = nullptr; m.dtcnt = nullptr; m.dtlog_cap = 0; m.ylog = nullptr; m.yend = nullptr;
   if (m.with_ode) {
     IntegTableau t;
     fill_tableau(c.ode_solver, t);
@@ -1994,10 +2002,71 @@ static int fill_train_model(odevio_plan* p, TrainModel& m) {
 // 8 x the room (up to TRAIN_DTLOG_CAP_MAX); euler (no error estimate: every dt0 step is accepted) is sized from the longest interval the caller could mean
 #define TRAIN_DTLOG_CAP 64
 #define TRAIN_DTLOG_CAP_MAX 16384
+#define TRAIN_YLOG_MAX_FLOATS ((size_t)256 << 20)   // 1 GiB: beyond it the states are not logged and the tape walks the steps in order
 
-extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
-                                  const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
-                                  const odevio_tensor* grads, int32_t n_grads, void* stream) {
+// The log of one forward as one run of floats: [dtlog rows*P*cap][dtcnt rows*P (ints)][yend rows*P*F][ylog rows*P*cap*F]; the last two
+// are absent (with_y = false) when they would not fit TRAIN_YLOG_MAX_FLOATS or the plan has no ODE.
+struct TapeLayout {
+  int cap = 0, R = 0;
+  bool with_y = false;
+  size_t n_dt = 0, n_cnt = 0, n_yend = 0, n_ylog = 0;
+  size_t total() const { return n_dt + n_cnt + n_yend + n_ylog; }
+  StepLog carve(float* base) const {
+    StepLog l;
+    l.cap = cap;
+    l.dtlog = base;
+    l.dtcnt = reinterpret_cast<int*>(base + n_dt);
+    if (with_y) { l.yend = base + n_dt + n_cnt; l.ylog = l.yend + n_yend; }
+    return l;
+  }
+};
+static TapeLayout tape_layout(const odevio_plan* p, int B, int P, int cap) {
+  TapeLayout t;
+  t.cap = cap;
+  t.R = p->cfg.rnn_num_layers * B;
+  const size_t rp = (size_t)t.R * P;
+  t.n_dt = (rp * cap + 3) / 4 * 4;
+  t.n_cnt = (rp + 3) / 4 * 4;
+  const bool in_order = getenv("ODEVIO_TAPE_IN_ORDER") != nullptr;   // diagnostic / tests: the step-by-step tape although the states would fit (read per call)
+  t.with_y = p->cfg.model_type == ODEVIO_MODEL_ODE_RNN && rp * cap * p->F <= TRAIN_YLOG_MAX_FLOATS && !in_order;
+  if (t.with_y) { t.n_yend = rp * p->F; t.n_ylog = rp * cap * p->F; }
+  return t;
+}
+// the log's room per interval for this plan's solver: fixed-step solvers take exactly ode_substeps steps
+static int tape_default_cap(const odevio_plan* p) {
+  if (is_fixed_step(p->cfg.ode_solver)) return std::max(1, p->cfg.ode_substeps);
+  IntegTableau tb;
+  fill_tableau(p->cfg.ode_solver, tb);
+  return tb.has_err ? TRAIN_DTLOG_CAP : std::min(TRAIN_DTLOG_CAP_MAX, std::max(TRAIN_DTLOG_CAP, p->cfg.max_steps));
+}
+
+extern "C" int odevio_ode_rnn_tape_floats(const odevio_plan* p, int32_t B, int32_t P, int64_t* n_floats) {
+  ARGCHK(p && n_floats && B > 0 && P > 0, "odevio_ode_rnn_tape_floats: bad argument");
+  *n_floats = 0;
+  if (p->cfg.model_type != ODEVIO_MODEL_ODE_RNN) return ODEVIO_OK;   // nothing a tape would save: the plain pair does the same work
+  *n_floats = (int64_t)tape_layout(p, B, P, tape_default_cap(p)).total();
+  return ODEVIO_OK;
+}
+
+extern "C" int odevio_ode_rnn_fwd_taped(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
+                                        float* poses, float* h_T, float* tape, int64_t tape_floats, void* stream) {
+  ARGCHK(p && fused && ts && poses && h_T && tape && B > 0 && P > 0, "odevio_ode_rnn_fwd_taped: bad argument");
+  if (p->cfg.model_type != ODEVIO_MODEL_ODE_RNN) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_ode_rnn_fwd_taped: ode-rnn plans only");
+  const TapeLayout t = tape_layout(p, B, P, tape_default_cap(p));
+  if ((int64_t)t.total() != tape_floats)
+    return fail(ODEVIO_ERR_BAD_ARG, "odevio_ode_rnn_fwd_taped: tape of %lld floats, odevio_ode_rnn_tape_floats says %lld", (long long)tape_floats, (long long)t.total());
+  hipStream_t st = (hipStream_t)stream;
+  POLL(p, st);
+  const StepLog log = t.carve(tape);
+  HIPCHK(hipMemsetAsync(log.dtcnt, 0, t.n_cnt * sizeof(int), st));
+  const int rc = ode_rnn_fwd(p, fused, ts, hc_in, B, P, poses, h_T, nullptr, st, log);
+  post_status(p, st);
+  return rc;
+}
+
+static int ode_rnn_bwd_impl(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
+                            const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
+                            const odevio_tensor* grads, int32_t n_grads, const float* tape, int64_t tape_floats, void* stream) {
   ARGCHK(p && fused && ts && grad_poses && B > 0 && P > 0 && n_grads >= 0 && (grads || n_grads == 0), "odevio_ode_rnn_bwd: bad argument");
   if (grad_hc && !hc_in) return fail(ODEVIO_ERR_BAD_ARG, "odevio_ode_rnn_bwd: grad_hc without hc_in");
   hipStream_t st = (hipStream_t)stream;
@@ -2036,39 +2105,71 @@ extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const floa
     if (want != grads[i].numel)
       return fail(ODEVIO_ERR_BAD_ARG, "odevio_ode_rnn_bwd: gradient '%s' has %lld elements, expected %lld", nm.c_str(), (long long)grads[i].numel, (long long)want);
   }
-  if (m.adaptive) {
-    // the forward once more on the persistent kernel, this time logging every accepted step size per row and interval;
-    // the host needs ONE number from it (the largest step count, which sizes the replay)
-    const int R = m.L * B;
-    IntegTableau tb;
-    fill_tableau(p->cfg.ode_solver, tb);
-    int cap = tb.has_err ? TRAIN_DTLOG_CAP : std::min(TRAIN_DTLOG_CAP_MAX, std::max(TRAIN_DTLOG_CAP, p->cfg.max_steps));
-    for (int attempt = 0;; ++attempt) {
-      const size_t n_log = (size_t)R * P * cap, n_cnt = (size_t)R * P;
-      if ((rc = ensure(p->train_log, n_log + n_cnt + (size_t)R * F)) || (rc = ensure(p->out_seq, (size_t)B * P * F))) return rc;
-      float* dtlog = p->train_log.p;
-      int* dtcnt = reinterpret_cast<int*>(p->train_log.p + n_log);
-      float* hT_tmp = p->train_log.p + n_log + n_cnt;
-      HIPCHK(hipMemsetAsync(dtcnt, 0, n_cnt * sizeof(int), st));
-      if ((rc = run_sequence(p, fused, ts, hc_in, B, P, p->out_seq.p, hT_tmp, nullptr, st, dtlog, dtcnt, cap))) return rc;
+  if (m.with_ode) {
+    // The log of the forward's accepted steps (their sizes, the states they start from, the evolved state of every interval): the
+    // caller's tape from odevio_ode_rnn_fwd_taped, or - without one - the forward once more on the persistent kernel.  The host
+    // needs ONE number from it (the largest step count, which sizes the replay).  A log that turns out too short for an interval is
+    // written again with 8 x the room.
+    int cap = tape_default_cap(p);
+    TapeLayout t = tape_layout(p, B, P, cap);
+    StepLog log;
+    bool have = false;
+    if (tape) {
+      if ((int64_t)t.total() != tape_floats)
+        return fail(ODEVIO_ERR_BAD_ARG, "odevio_ode_rnn_bwd_taped: tape of %lld floats, odevio_ode_rnn_tape_floats says %lld", (long long)tape_floats, (long long)t.total());
+      log = t.carve(const_cast<float*>(tape));
+      have = true;
+    }
+    const bool want_log = m.adaptive || have || t.with_y;   // a fixed-step solve whose states would not fit is replayed in order, from ts alone
+    for (int attempt = 0; want_log; ++attempt) {
+      if (!have) {
+        t = tape_layout(p, B, P, cap);
+        if ((rc = ensure(p->train_log, t.total() + (size_t)t.R * F)) || (rc = ensure(p->out_seq, (size_t)B * P * F))) return rc;
+        log = t.carve(p->train_log.p);
+        float* hT_tmp = p->train_log.p + t.total();
+        HIPCHK(hipMemsetAsync(log.dtcnt, 0, t.n_cnt * sizeof(int), st));
+        if ((rc = run_sequence(p, fused, ts, hc_in, B, P, p->out_seq.p, hT_tmp, nullptr, st, log))) return rc;
+      }
+      if (!m.adaptive) break;                                  // fixed-step: ode_substeps steps everywhere, nothing to read back
+      const size_t n_cnt = (size_t)t.R * P;
       std::vector<int> cnt(n_cnt);
-      HIPCHK(hipMemcpyAsync(cnt.data(), dtcnt, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(cnt.data(), log.dtcnt, n_cnt * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      rc = odevio_check(p, stream);     // a step budget / log overflow of that forward
-      if (rc == ODEVIO_ERR_MAX_STEPS && attempt < 3 && cap < TRAIN_DTLOG_CAP_MAX) {
-        cap = std::min(TRAIN_DTLOG_CAP_MAX, cap * 8);   // the forward itself succeeded when it produced these inputs: the LOG was too short
+      if (!have && (rc = odevio_check(p, stream))) return rc;     // that forward's own failures (step budget, ...)
+      const int most = *std::max_element(cnt.begin(), cnt.end());
+      if (most > t.cap) {
+        if (attempt >= 3 || t.cap >= TRAIN_DTLOG_CAP_MAX)
+          return fail(ODEVIO_ERR_MAX_STEPS, "odevio_ode_rnn_bwd: an interval took %d accepted steps, the log holds at most %d", most, TRAIN_DTLOG_CAP_MAX);
+        cap = std::min(TRAIN_DTLOG_CAP_MAX, t.cap * 8);
+        have = false;
         continue;
       }
-      if (rc) return rc;
-      m.jmax = std::max(1, *std::max_element(cnt.begin(), cnt.end()));
-      m.dtlog = dtlog; m.dtcnt = dtcnt; m.dtlog_cap = cap;
+      m.jmax = std::max(1, most);
       break;
+    }
+    if (want_log) {
+      m.dtcnt = log.dtcnt; m.dtlog_cap = t.cap;
+      m.dtlog = m.adaptive ? log.dtlog : nullptr;
+      m.ylog = log.ylog; m.yend = log.yend;
     }
   }
   if ((rc = ensure(p->train_ws, train_workspace_floats(m, B, P)))) return rc;
   rc = train_ode_rnn_bwd(m, p->train_ws.p, fused, ts, hc_in, B, P, grad_poses, grad_hT, grad_fused, grad_hc, g, st);
   if (rc) return fail(rc, "odevio_ode_rnn_bwd: %s", hipGetErrorString(hipGetLastError()));
   return 0;
+}
+
+extern "C" int odevio_ode_rnn_bwd(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
+                                  const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
+                                  const odevio_tensor* grads, int32_t n_grads, void* stream) {
+  return ode_rnn_bwd_impl(p, fused, ts, hc_in, B, P, grad_poses, grad_hT, grad_fused, grad_hc, grads, n_grads, nullptr, 0, stream);
+}
+
+extern "C" int odevio_ode_rnn_bwd_taped(odevio_plan* p, const float* fused, const float* ts, const float* hc_in, int32_t B, int32_t P,
+                                        const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc,
+                                        const odevio_tensor* grads, int32_t n_grads, const float* tape, int64_t tape_floats, void* stream) {
+  ARGCHK(tape, "odevio_ode_rnn_bwd_taped: no tape");
+  return ode_rnn_bwd_impl(p, fused, ts, hc_in, B, P, grad_poses, grad_hT, grad_fused, grad_hc, grads, n_grads, tape, tape_floats, stream);
 }
 
 // odevio_plan_update: the index maps of load_pose_net as device kernels, from the caller's device tensors straight into the

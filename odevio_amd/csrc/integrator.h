@@ -57,11 +57,15 @@ struct IntegArgs {
   float* y_out;                           // [rows][F]
   int* stats;                             // [rows][2] or null
   // accepted-step log for the backward (train.hip replays the forward's accepted steps): dtlog [rows][P][dtlog_cap] step
-  // sizes in order, dtcnt [rows][P] how many; null = no log.  More than dtlog_cap accepted steps in one interval raise the
-  // step-budget status.
+  // sizes in order, dtcnt [rows][P] how many ACCEPTED steps the interval took (a count above dtlog_cap says the log is
+  // incomplete; the forward itself is not affected); null = no log.  ylog [rows][P][dtlog_cap][Fio] (optional, with dtlog): the
+  // state each accepted step starts from, yend [rows][P][Fio]: the evolved state at the end of the interval - with these the
+  // backward rebuilds every stage of every step in ONE batch instead of walking the steps in order.
   float* dtlog;
   int* dtcnt;
   int dtlog_cap;
+  float* ylog;
+  float* yend;
   // ---- infrastructure
   unsigned long long* xbuf;               // [G][2][xstride] 8-byte {tag, value} granules
   int xstride;

@@ -607,9 +607,12 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
         if (running) ++n_steps;
         if (upd) {
           ++n_acc;
-          if (logger) {
-            if (acc_it < a.dtlog_cap) a.dtlog[((size_t)grow * a.P + it) * a.dtlog_cap + acc_it] = dt;
-            else atomicCAS(c.status, 0, ST_MAX_STEPS);
+          // the log of the backward: this step's size (one thread per row) and the state it starts from (every owner its element).
+          // A log too short for the interval is not an error of the forward: the count keeps running and the host sees it.
+          if (acc_it < a.dtlog_cap) {
+            if (logger) a.dtlog[((size_t)grow * a.P + it) * a.dtlog_cap + acc_it] = dt;
+            if (a.ylog && seq_mode && row_valid && owner && ocg < Fio)
+              a.ylog[(((size_t)grow * a.P + it) * a.dtlog_cap + acc_it) * Fio + ocg] = y;
           }
           ++acc_it;
           y = y1;
@@ -630,7 +633,8 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
         }
         have_k1 = a.tab.fsal != 0;
       }
-      if (logger) a.dtcnt[(size_t)grow * a.P + it] = min(acc_it, a.dtlog_cap);
+      if (logger) a.dtcnt[(size_t)grow * a.P + it] = acc_it;   // may exceed dtlog_cap: then the log is incomplete and the host asks again
+      if (a.ylog && seq_mode && row_valid && owner && ocg < Fio) a.yend[((size_t)grow * a.P + it) * Fio + ocg] = y;   // the evolved state the RNN sees
       if (!seq_mode) break;
     }
     if (!seq_mode || c.failed) break;

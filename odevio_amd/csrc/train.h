@@ -27,6 +27,10 @@ struct TrainModel {
   const float* dtlog;
   const int* dtcnt;
   int dtlog_cap;
+  // optional, from a logging forward (integrator.h): ylog [rows][P][dtlog_cap][F] the state each accepted step starts from, yend
+  // [rows][P][F] the evolved state of each interval (+ dtcnt).  With them the tape is rebuilt in one batch over all steps.
+  const float* ylog;
+  const float* yend;
 };
 
 // Where the weight gradients go (device pointers, same shapes as the reference's parameters; null = not wanted).

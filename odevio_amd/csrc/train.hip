@@ -70,13 +70,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * q;
   const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 16 * wave; k < K; k += 64) {
-    // K % 4 == 0: a lane's four consecutive k are inside K or all outside (the tail of a K that is not a multiple of 16 adds zeros)
-    const bool in = k + 4 * q < K;
-    const f32x4 wv = in ? *reinterpret_cast<const f32x4*>(wrow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 av = in ? *reinterpret_cast<const f32x4*>(arow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // A wave's k-steps (16 * wave, += 64) eight at a time: the sixteen 16-byte loads of a batch are issued before the first MFMA
+  // waits on one, so a K = 512 row costs one round trip to L2, not eight in a chain (these products are latency, not bandwidth:
+  // 7.5 us -> see profiles/r03_train_step.txt).  Same products in the same order as a one-step loop.
+  for (int k0 = 16 * wave; k0 < K; k0 += 512) {
+    f32x4 wv[8], av[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u) {
+      // K % 4 == 0: a lane's four consecutive k are inside K or all outside (a tail adds zeros); the ADDRESS is clamped and the
+      // VALUE selected, so that no load sits behind a branch
+      const int k = k0 + 64 * u + 4 * q;
+      const bool in = k < K;
+      const int kc = in ? k - 4 * q : 0;
+      wv[u] = *reinterpret_cast<const f32x4*>(wrow + kc);
+      av[u] = *reinterpret_cast<const f32x4*>(arow + kc);
+      if (!in) { wv[u] = f32x4{0.f, 0.f, 0.f, 0.f}; av[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], av[u][j], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];   // [n local][m local]
@@ -93,29 +106,49 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   }
 }
 
+// bias_out (optional): the column sums of D (out_b[n] = sum_m D[m][n], the bias gradient that goes with a weight gradient) from the
+// same launch: one more column of workgroups (blockIdx.x == tiles of K) contracts D with a column of ones.
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ A, int lda,
-                                                      float* __restrict__ out, int ldo, int M, int N, int K, int accumulate) {
+                                                      float* __restrict__ out, int ldo, int M, int N, int K, int accumulate,
+                                                      float* __restrict__ bias_out) {
   __shared__ float red[4][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
+  const bool ones = (int)blockIdx.x * 16 >= K;   // the bias column
   const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
   const int nn = min(n0 + r, N - 1), kk = min(k0 + r, K - 1);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  // contraction over rows m: MFMA j of a 16-row step uses rows m = 16 s + 4 q + j
-  for (int mb = 16 * wave; mb < M; mb += 64) {
+  // contraction over rows m: MFMA j of a 16-row step uses rows m = 16 s + 4 q + j; four steps' loads are issued together
+  for (int mb = 16 * wave; mb < M; mb += 256) {
+    float dv[4][4], av[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = mb + 4 * q + j;
-      const float dv = m < M ? D[(size_t)m * ldd + nn] : 0.f;
-      const float av = m < M ? A[(size_t)m * lda + kk] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, av, acc, 0, 0, 0);   // D rows = n, D columns = k
-    }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = mb + 64 * u + 4 * q + j;
+        const int mc = m < M ? m : 0;
+        const float d = D[(size_t)mc * ldd + nn];
+        const float a = ones ? (r == 0 ? 1.f : 0.f) : A[(size_t)mc * lda + kk];
+        dv[u][j] = m < M ? d : 0.f;
+        av[u][j] = m < M ? a : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][j], av[u][j], acc, 0, 0, 0);   // D rows = n, D columns = k
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];   // [n local][k local]
   __syncthreads();
   const int nl = tid >> 4, kl = tid & 15;
   const int n = n0 + nl, k = k0 + kl;
+  if (ones) {
+    if (kl == 0 && n < N) {
+      const float v = (red[0][nl][0] + red[1][nl][0]) + (red[2][nl][0] + red[3][nl][0]);
+      bias_out[n] = accumulate ? bias_out[n] + v : v;
+    }
+    return;
+  }
   if (n < N && k < K) {
     const float v = (red[0][nl][kl] + red[1][nl][kl]) + (red[2][nl][kl] + red[3][nl][kl]);
     float* o = out + (size_t)n * ldo + k;
@@ -129,8 +162,9 @@ static void gemm_nt(hipStream_t st, const float* A, int lda, const float* W, int
                      accumulate ? 1 : 0, epi, act, aux, ldaux);
 }
 static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K,
-                    bool accumulate = false) {
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((K + 15) / 16, (N + 15) / 16), dim3(256), 0, st, D, ldd, A, lda, out, ldo, M, N, K, accumulate ? 1 : 0);
+                    bool accumulate = false, float* bias_out = nullptr) {
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((K + 15) / 16 + (bias_out ? 1 : 0), (N + 15) / 16), dim3(256), 0, st, D, ldd, A, lda, out, ldo, M, N, K,
+                     accumulate ? 1 : 0, bias_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -140,6 +174,7 @@ static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int
 #define EW_LOOP(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); i += (size_t)gridDim.x * blockDim.x)
 
 __global__ void act_kernel(float* x, size_t n, int act) { EW_LOOP(i, n) x[i] = tr_act(x[i], act); }
+__global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) { EW_LOOP(i, n) b[i] = a[i]; }
 
 // dt[it][j][r]: fixed-step solvers: (ts[b][it+1] - ts[b][it]) / J with b = r % B (the relative shift of PoseODERNN.py:100
 // cancels in the difference); adaptive solvers: the j-th ACCEPTED step of row r in interval it from the forward's log, or
@@ -227,9 +262,10 @@ __global__ void gru_cell_kernel(const float* __restrict__ gi, const float* __res
   }
 }
 // g = dL/dh' -> delta_i [B][3F] (w.r.t. gi), delta_h [B][3F] (w.r.t. gh), dhp_direct [B][F] = g * z
-__global__ void gru_cell_bwd_kernel(const float* __restrict__ g, const float* __restrict__ g2, const float* __restrict__ gates,
+// (g and dhp_direct may be the same buffer: element i is read, then written, by the same thread)
+__global__ void gru_cell_bwd_kernel(const float* g, const float* __restrict__ g2, const float* __restrict__ gates,
                                     const float* __restrict__ hp, float* __restrict__ di, float* __restrict__ dh,
-                                    float* __restrict__ dhp_direct, int B, int F) {
+                                    float* dhp_direct, int B, int F) {
   EW_LOOP(i, (size_t)B * F) {
     const size_t b = i / F, c = i % F;
     const float* gt = gates + b * 4 * F;
@@ -250,25 +286,6 @@ __global__ void add_kernel(float* __restrict__ x, const float* __restrict__ y, s
 __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a, float* __restrict__ delta, size_t n, int act) {
   EW_LOOP(i, n) delta[i] = g[i] * tr_act_grad(a[i], act);
 }
-// start of a step's adjoint: lamK_s = dt[r] * b_s * lam
-__global__ void step_adjoint_init_kernel(const float* __restrict__ lam, float* __restrict__ lamK, size_t kstride, StageCoef b,
-                                         const float* __restrict__ dt, int R, int F) {
-  EW_LOOP(i, (size_t)R * F) {
-    const int r = (int)(i / F);
-    for (int s = 0; s < b.n; ++s) lamK[s * kstride + i] = dt[r] * b.c[s] * lam[i];
-  }
-}
-// after stage s: lam += gX;  lamK_j += dt[r] * a_sj * gX for j < s
-__global__ void stage_adjoint_kernel(float* __restrict__ lam, float* __restrict__ lamK, size_t kstride, const float* __restrict__ gX,
-                                     StageCoef a, const float* __restrict__ dt, int R, int F) {
-  EW_LOOP(i, (size_t)R * F) {
-    const int r = (int)(i / F);
-    const float g = gX[i];
-    lam[i] += g;
-    for (int j = 0; j < a.n; ++j)
-      if (a.c[j] != 0.f) lamK[j * kstride + i] += dt[r] * a.c[j] * g;
-  }
-}
 // column sums of a [M][N] matrix (bias gradients); one thread per column, rows in order (deterministic)
 // out[n] = sum over the M rows of x[m][n].  One 256-thread block per 32 columns: 8 row groups stride the rows (each thread adds its
 // rows in order), then the 8 partial sums are combined in group order - deterministic, and M (up to intervals x steps x stages x
@@ -278,8 +295,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int n = blockIdx.x * 32 + c;
   float s = 0.f;
-  if (n < N)
-    for (int m = g; m < M; m += 8) s += x[(size_t)m * N + n];
+  if (n < N) {
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains (rows m, m + 8, m + 16, m + 24 of a 32-row step): loads in flight, fixed order
+    int m = g;
+    for (; m + 24 < M; m += 32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += x[(size_t)(m + 8 * u) * N + n];
+    }
+    for (int u = 0; m < M; m += 8, ++u) s4[u] += x[(size_t)m * N + n];
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
   red[g][c] = s;
   __syncthreads();
   if (g == 0 && n < N) {
@@ -291,6 +316,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 static void launch_colsum(hipStream_t st, const float* x, float* out, int M, int N) {
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, st, x, out, M, N);
+}
+// weight gradient gw = D^T A and bias gradient gb = column sums of D; both wanted: one launch
+static void wgrad_bias(hipStream_t st, const float* D, int ldd, const float* A, int lda, float* gw, int ldo, float* gb, int M, int N, int K) {
+  if (gw) gemm_tn(st, D, ldd, A, lda, gw, ldo, M, N, K, false, ldd == N ? gb : nullptr);
+  if (gb && !(gw && ldd == N)) launch_colsum(st, D, gb, M, N);
 }
 // regressor.2 backward: dhid[m][k] = (sum_n dp[m][n] W2[n][k]) * leaky'(hid[m][k])   (6 outputs: no GEMM needed)
 __global__ void reg2_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ W2, const float* __restrict__ hid,
@@ -336,6 +366,103 @@ int train_pose_loss(const float* poses, const float* gts, int M, float* loss3, f
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// kernels of the batched tape and of the fused reverse sweep
+// ---------------------------------------------------------------------------------------------------------------------
+// the state every accepted step starts from, for all intervals and steps at once: Y[(it * J + j) * R + r] = the forward's log
+// (ylog [r][P][cap][F]) for j < cnt[r][it], the interval's evolved state (yend [r][P][F]) for the zero-length steps behind them
+__global__ void ylog_rows_kernel(const float* __restrict__ ylog, const float* __restrict__ yend, const int* __restrict__ cnt, float* __restrict__ Y,
+                                 int P, int J, int R, int cap, int F) {
+  EW_LOOP(i, (size_t)P * J * R * F) {
+    const int f = (int)(i % F);
+    const size_t row = i / F;
+    const int r = (int)(row % R), j = (int)((row / R) % J), it = (int)(row / ((size_t)R * J));
+    const size_t ri = (size_t)r * P + it;
+    Y[i] = j < cnt[ri] ? ylog[(ri * cap + j) * F + f] : yend[ri * F + f];
+  }
+}
+// [B][P][C] -> interval-major [P][B][C] (all intervals in one launch) and the RNN's hidden inputs of layer l from yend
+__global__ void to_interval_major_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int P, int C) {
+  EW_LOOP(i, (size_t)P * B * C) {
+    const int c = (int)(i % C), b = (int)((i / C) % B), it = (int)(i / ((size_t)C * B));
+    dst[i] = src[((size_t)b * P + it) * C + c];
+  }
+}
+__global__ void yend_rows_kernel(const float* __restrict__ yend, float* __restrict__ hp, int l, int B, int P, int F) {
+  EW_LOOP(i, (size_t)P * B * F) {
+    const int f = (int)(i % F), b = (int)((i / F) % B), it = (int)(i / ((size_t)F * B));
+    hp[i] = yend[(((size_t)l * B + b) * P + it) * F + f];
+  }
+}
+// start of a step's adjoint: lamK_s = dt[r] * b_s * lam for every stage, and the pre-activation gradient of the LAST stage's final
+// Linear (K = tanh(.)): delta = lamK_{S-1} * (1 - K_{S-1}^2)
+__global__ void step_adjoint_init_kernel(const float* __restrict__ lam, float* __restrict__ lamK, size_t kstride, StageCoef b,
+                                         const float* __restrict__ dt, const float* __restrict__ Klast, float* __restrict__ delta_last, int R, int F) {
+  EW_LOOP(i, (size_t)R * F) {
+    const int r = (int)(i / F);
+    float last = 0.f;
+    for (int s = 0; s < b.n; ++s) {
+      last = dt[r] * b.c[s] * lam[i];
+      lamK[s * kstride + i] = last;
+    }
+    const float k = Klast[i];
+    delta_last[i] = last * (1.f - k * k);
+  }
+}
+// The product that ends a stage's adjoint, gX = delta_0 W_0 (gemm_nt_kernel's tile), with the stage bookkeeping as its epilogue:
+//   lam += gX;  lamK_j += dt[r] * a_sj * gX for j < s;  and, for the stage below, delta = lamK_{s-1} * (1 - K_{s-1}^2).
+struct AdjEpi {
+  float* lam;
+  float* lamK;
+  size_t kstride;
+  StageCoef a;
+  const float* dt;
+  const float* Kprev;    // K_{s-1} rows of this step (null at s = 0)
+  float* delta_prev;     // where the stage below expects its last-Linear gradient
+};
+__global__ __launch_bounds__(256) void gemm_nt_adj_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int M, int N, int K,
+                                                          AdjEpi e) {
+  __shared__ float red[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * q;
+  const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 16 * wave; k0 < K; k0 += 512) {
+    f32x4 wv[8], av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 64 * u + 4 * q;
+      const bool in = k < K;
+      const int kc = in ? k - 4 * q : 0;
+      wv[u] = *reinterpret_cast<const f32x4*>(wrow + kc);
+      av[u] = *reinterpret_cast<const f32x4*>(arow + kc);
+      if (!in) { wv[u] = f32x4{0.f, 0.f, 0.f, 0.f}; av[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], av[u][j], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int x = 0; x < 4; ++x) red[wave][4 * q + x][r] = acc[x];
+  __syncthreads();
+  const int nl = tid >> 4, ml = tid & 15;
+  const int n = n0 + nl, m = m0 + ml;
+  if (n < N && m < M) {
+    const float g = (red[0][nl][ml] + red[1][nl][ml]) + (red[2][nl][ml] + red[3][nl][ml]);
+    const size_t i = (size_t)m * N + n;
+    e.lam[i] += g;
+    for (int j = 0; j < e.a.n; ++j)
+      if (e.a.c[j] != 0.f) e.lamK[j * e.kstride + i] += e.dt[m] * e.a.c[j] * g;
+    if (e.Kprev) {
+      const float k = e.Kprev[i];
+      e.delta_prev[i] = e.lamK[(size_t)(e.a.n - 1) * e.kstride + i] * (1.f - k * k);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 size_t train_workspace_floats(const TrainModel& m, int B, int P) {
   const int R = m.L * B, S = m.stages;
   const size_t M = (size_t)P * m.jmax * S * R, MB = (size_t)P * B;
@@ -343,23 +470,28 @@ size_t train_workspace_floats(const TrainModel& m, int B, int P) {
   for (int l = 0; l <= m.nlin; ++l) n += M * m.dims[l];          // act
   for (int l = 0; l < m.nlin; ++l) n += M * m.dims[l + 1];       // delta
   n += ((size_t)P * m.jmax * R + 3) / 4 * 4;                     // dt (kept 16-byte aligned: the GEMM operands behind it are read as float4)
-  n += 3 * (size_t)R * m.F;                                      // Y, lam, gX
+  n += 2 * (size_t)R * m.F;                                      // Y, lam
   n += 8 * (size_t)R * m.F;                                      // lamK
-  n += (size_t)R * std::max(m.F, m.H);                           // scratch g
   const size_t G = m.gru ? 3 : 1;
   n += (size_t)m.L * MB * m.F * (3 + G);                         // rnn_in, rnn_hp, rnn_out, rnn_delta (GRU: [MB][3F])
   if (m.gru) n += (size_t)m.L * MB * m.F * (3 + 4);              // GRU: delta w.r.t. gh [MB][3F], gates [MB][4F]
-  n += (2 * G + 3) * (size_t)B * m.F;                            // gi, gh ([B][G*F] each), dinp, dhp, dhp_direct
+  n += 2 * G * MB * m.F;                                         // gi, gh ([P*B][G*F] each: the batched tape does every interval at once)
+  n += (size_t)B * m.F;                                          // dinp
   n += MB * 128 * 2 + (MB * 6 + 3) / 4 * 4 + MB * m.F;           // hid, dhid, dposes (interval-major), dout
   return n;
 }
 
+// Tape rows: stage s of step j of interval it, row r  ->  ((s * P + it) * J + j) * R + r  (a STAGE's rows of all steps are contiguous,
+// which is what lets the batched tape run one product per stage and layer over every step of the window)
 int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const float* ts, const float* hc, int B, int P,
                       const float* grad_poses, const float* grad_hT, float* grad_fused, float* grad_hc, const TrainGrads& g,
                       hipStream_t st) {
   const int L = m.L, F = m.F, R = L * B, S = m.stages, nl = m.nlin;
   const int J = m.jmax;
-  const size_t M = (size_t)P * J * S * R, MB = (size_t)P * B, RF = (size_t)R * F;
+  const size_t PJR = (size_t)P * J * R;
+  const size_t M = PJR * S, MB = (size_t)P * B, RF = (size_t)R * F, BF = (size_t)B * F;
+  const size_t kstride = PJR * F;                                  // from K_s to K_{s+1} of the same step
+  auto row0 = [&](int it, int j, int s) { return (size_t)s * PJR + ((size_t)it * J + j) * R; };
   // ---- carve the workspace
   float* q = ws;
   float* act[TRAIN_MAX_LIN + 1];
@@ -369,9 +501,7 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
   float* dt = q; q += ((size_t)P * J * R + 3) / 4 * 4;
   float* Y = q; q += RF;
   float* lam = q; q += RF;
-  float* gX = q; q += RF;
   float* lamK = q; q += 8 * RF;
-  q += (size_t)R * std::max(F, m.H);   // (scratch of the unfused reverse sweep; the layout of the workspace is kept)
   const int G = m.gru ? 3 : 1, GF = G * F;     // gate rows per hidden unit
   float *rnn_in[TRAIN_MAX_L], *rnn_hp[TRAIN_MAX_L], *rnn_out[TRAIN_MAX_L], *rnn_delta[TRAIN_MAX_L];
   float *rnn_delta_h[TRAIN_MAX_L] = {}, *rnn_gates[TRAIN_MAX_L] = {};
@@ -380,11 +510,9 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
     if (m.gru) { rnn_delta_h[l] = q; q += MB * GF; rnn_gates[l] = q; q += MB * 4 * F; }
     else rnn_delta_h[l] = rnn_delta[l];      // tanh RNN: one delta serves W_ih and W_hh
   }
-  float* gi = q; q += (size_t)B * GF;
-  float* gh = q; q += (size_t)B * GF;
-  float* dinp = q; q += (size_t)B * F;
-  float* dhp = q; q += (size_t)B * F;
-  float* dhp_direct = q; q += (size_t)B * F;
+  float* gi = q; q += MB * GF;
+  float* gh = q; q += MB * GF;
+  float* dinp = q; q += BF;
   float* hid = q; q += MB * 128;
   float* dhid = q; q += MB * 128;
   float* dpo = q; q += (MB * 6 + 3) / 4 * 4;
@@ -400,41 +528,63 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
 
   // =============================== 1. tape ===============================
   hipLaunchKernelGGL(dt_rows_kernel, EW_GRID((size_t)P * J * R), 0, st, ts, dt, B, P, R, J, m.adaptive ? m.dtlog : nullptr, m.dtcnt, m.dtlog_cap);
-  if (hc) (void)hipMemcpyAsync(Y, hc, RF * sizeof(float), hipMemcpyDeviceToDevice, st);
-  else (void)hipMemsetAsync(Y, 0, RF * sizeof(float), st);
-  for (int it = 0; it < P; ++it) {
-    if (m.with_ode) {
-      for (int j = 0; j < J; ++j) {
-        const float* dtp = dt + ((size_t)it * J + j) * R;                   // this step's size, per row
-        const size_t mstep = ((size_t)it * J + j) * S * R;                  // first tape row of this step
-        const float* kbase = act[nl] + mstep * F;                           // K_0 of this step; K_s is S*... rows later
-        for (int s = 0; s < S; ++s) {
-          const size_t m0 = mstep + (size_t)s * R;
-          hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, act[0] + m0 * F, Y, kbase, RF, arow[s], dtp, R, F);
-          for (int l = 0; l < nl; ++l) {
-            float* o = act[l + 1] + m0 * m.dims[l + 1];
-            gemm_nt(st, act[l] + m0 * m.dims[l], m.dims[l], m.ode_w[l], m.dims[l], m.ode_b[l], o, m.dims[l + 1], R, m.dims[l + 1], m.dims[l], false,
-                    GEPI_ACT, l + 1 < nl ? m.act : 0);   // Linear + activation (the last one: Tanh, ODEFunc.py:13-14) in one launch
-          }
-        }
-        // Y <- Y + dt * sum_s b_s K_s: the stage-input formula with the b row
-        hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, Y, Y, kbase, RF, brow, dtp, R, F);
-      }
+  const bool batched = m.with_ode && m.ylog && m.yend && m.dtcnt;
+  if (batched) {
+    // Every step's starting state is in the forward's log: the stages of ALL steps of the window are rebuilt together, stage by
+    // stage (S x (1 + layers) launches with P*J*R rows each, instead of that many per step), and the RNN cells of all intervals
+    // layer by layer (their hidden inputs are the logged evolved states).
+    hipLaunchKernelGGL(ylog_rows_kernel, EW_GRID(PJR * F), 0, st, m.ylog, m.yend, m.dtcnt, act[0], P, J, R, m.dtlog_cap, F);
+    for (int s = 0; s < S; ++s) {
+      if (s > 0)
+        hipLaunchKernelGGL(stage_input_kernel, EW_GRID(PJR * F), 0, st, act[0] + (size_t)s * PJR * F, act[0], act[nl], kstride, arow[s], dt, (int)PJR, F);
+      for (int l = 0; l < nl; ++l)
+        gemm_nt(st, act[l] + (size_t)s * PJR * m.dims[l], m.dims[l], m.ode_w[l], m.dims[l], m.ode_b[l], act[l + 1] + (size_t)s * PJR * m.dims[l + 1],
+                m.dims[l + 1], (int)PJR, m.dims[l + 1], m.dims[l], false, GEPI_ACT, l + 1 < nl ? m.act : 0);
     }
+    hipLaunchKernelGGL(to_interval_major_kernel, EW_GRID(MB * F), 0, st, fused, rnn_in[0], B, P, F);
     for (int l = 0; l < L; ++l) {
-      float* in_l = rnn_in[l] + (size_t)it * B * F;
-      float* hp_l = rnn_hp[l] + (size_t)it * B * F;
-      float* out_l = rnn_out[l] + (size_t)it * B * F;
-      if (l == 0) hipLaunchKernelGGL(gather_interval_kernel, EW_GRID((size_t)B * F), 0, st, fused, in_l, B, P, F, it);
-      else (void)hipMemcpyAsync(in_l, rnn_out[l - 1] + (size_t)it * B * F, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);
-      (void)hipMemcpyAsync(hp_l, Y + (size_t)l * B * F, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);
-      gemm_nt(st, in_l, F, m.rnn_wih[l], F, m.rnn_bih[l], gi, GF, B, GF, F);
-      gemm_nt(st, hp_l, F, m.rnn_whh[l], F, m.rnn_bhh[l], gh, GF, B, GF, F);
-      if (m.gru)
-        hipLaunchKernelGGL(gru_cell_kernel, EW_GRID((size_t)B * F), 0, st, gi, gh, hp_l, rnn_gates[l] + (size_t)it * B * 4 * F, out_l,
-                           Y + (size_t)l * B * F, B, F);
-      else
-        hipLaunchKernelGGL(rnn_cell_kernel, EW_GRID((size_t)B * F), 0, st, gi, gh, out_l, Y + (size_t)l * B * F, (size_t)B * F);
+      if (l > 0) rnn_in[l] = rnn_out[l - 1];     // (the layer below's outputs ARE this layer's inputs: no copy)
+      hipLaunchKernelGGL(yend_rows_kernel, EW_GRID(MB * F), 0, st, m.yend, rnn_hp[l], l, B, P, F);
+      gemm_nt(st, rnn_in[l], F, m.rnn_wih[l], F, m.rnn_bih[l], gi, GF, (int)MB, GF, F);
+      gemm_nt(st, rnn_hp[l], F, m.rnn_whh[l], F, m.rnn_bhh[l], gh, GF, (int)MB, GF, F);
+      if (m.gru) hipLaunchKernelGGL(gru_cell_kernel, EW_GRID(MB * F), 0, st, gi, gh, rnn_hp[l], rnn_gates[l], rnn_out[l], dout, (int)MB, F);
+      else hipLaunchKernelGGL(rnn_cell_kernel, EW_GRID(MB * F), 0, st, gi, gh, rnn_out[l], dout, MB * F);   // (dout: scratch until the sweep)
+    }
+  } else {
+    if (hc) hipLaunchKernelGGL(copy_kernel, EW_GRID(RF), 0, st, hc, Y, RF);
+    else (void)hipMemsetAsync(Y, 0, RF * sizeof(float), st);
+    for (int it = 0; it < P; ++it) {
+      if (m.with_ode) {
+        for (int j = 0; j < J; ++j) {
+          const float* dtp = dt + ((size_t)it * J + j) * R;                   // this step's size, per row
+          const float* kbase = act[nl] + row0(it, j, 0) * F;                  // K_0 of this step; K_s is kstride further
+          for (int s = 0; s < S; ++s) {
+            const size_t m0 = row0(it, j, s);
+            hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, act[0] + m0 * F, Y, kbase, kstride, arow[s], dtp, R, F);
+            for (int l = 0; l < nl; ++l) {
+              float* o = act[l + 1] + m0 * m.dims[l + 1];
+              gemm_nt(st, act[l] + m0 * m.dims[l], m.dims[l], m.ode_w[l], m.dims[l], m.ode_b[l], o, m.dims[l + 1], R, m.dims[l + 1], m.dims[l], false,
+                      GEPI_ACT, l + 1 < nl ? m.act : 0);   // Linear + activation (the last one: Tanh, ODEFunc.py:13-14) in one launch
+            }
+          }
+          // Y <- Y + dt * sum_s b_s K_s: the stage-input formula with the b row
+          hipLaunchKernelGGL(stage_input_kernel, EW_GRID(RF), 0, st, Y, Y, kbase, kstride, brow, dtp, R, F);
+        }
+      }
+      for (int l = 0; l < L; ++l) {
+        float* in_l = rnn_in[l] + (size_t)it * BF;
+        float* hp_l = rnn_hp[l] + (size_t)it * BF;
+        float* out_l = rnn_out[l] + (size_t)it * BF;
+        if (l == 0) hipLaunchKernelGGL(gather_interval_kernel, EW_GRID(BF), 0, st, fused, in_l, B, P, F, it);
+        else hipLaunchKernelGGL(copy_kernel, EW_GRID(BF), 0, st, rnn_out[l - 1] + (size_t)it * BF, in_l, BF);
+        hipLaunchKernelGGL(copy_kernel, EW_GRID(BF), 0, st, Y + (size_t)l * BF, hp_l, BF);
+        gemm_nt(st, in_l, F, m.rnn_wih[l], F, m.rnn_bih[l], gi, GF, B, GF, F);
+        gemm_nt(st, hp_l, F, m.rnn_whh[l], F, m.rnn_bhh[l], gh, GF, B, GF, F);
+        if (m.gru)
+          hipLaunchKernelGGL(gru_cell_kernel, EW_GRID(BF), 0, st, gi, gh, hp_l, rnn_gates[l] + (size_t)it * B * 4 * F, out_l, Y + (size_t)l * BF, B, F);
+        else
+          hipLaunchKernelGGL(rnn_cell_kernel, EW_GRID(BF), 0, st, gi, gh, out_l, Y + (size_t)l * BF, BF);
+      }
     }
   }
   // regressor hidden layer on the top-layer outputs (interval-major rows)
@@ -442,69 +592,66 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
   hipLaunchKernelGGL(leaky_kernel, EW_GRID(MB * 128), 0, st, hid, MB * 128, 0.1f);
 
   // =============================== 2. reverse sweep ===============================
-  for (int it = 0; it < P; ++it) hipLaunchKernelGGL(gather_interval_kernel, EW_GRID((size_t)B * 6), 0, st, grad_poses, dpo + (size_t)it * B * 6, B, P, 6, it);
+  hipLaunchKernelGGL(to_interval_major_kernel, EW_GRID(MB * 6), 0, st, grad_poses, dpo, B, P, 6);
   hipLaunchKernelGGL(reg2_bwd_kernel, EW_GRID(MB * 128), 0, st, dpo, m.reg_w2, hid, dhid, (int)MB);
   gemm_nt(st, dhid, 128, m.reg_w0_t, 128, nullptr, dout, F, (int)MB, F, 128);          // d out = dhid W0
-  if (grad_hT) (void)hipMemcpyAsync(lam, grad_hT, RF * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (grad_hT) hipLaunchKernelGGL(copy_kernel, EW_GRID(RF), 0, st, grad_hT, lam, RF);
   else (void)hipMemsetAsync(lam, 0, RF * sizeof(float), st);
   for (int it = P - 1; it >= 0; --it) {
-    // lam = dL/d(state after the RNN of interval it); the top layer's output also feeds the regressor
-    hipLaunchKernelGGL(add_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)(L - 1) * B * F, dout + (size_t)it * B * F, (size_t)B * F);
+    // lam = dL/d(state after the RNN of interval it); the top layer's output also feeds the regressor (dout) and, below the top,
+    // the layer above sent a gradient down its input (dinp): both enter the cell's backward as its second gradient
     for (int l = L - 1; l >= 0; --l) {
       float* d_l = rnn_delta[l] + (size_t)it * B * GF;
       float* dh_l = rnn_delta_h[l] + (size_t)it * B * GF;
-      // gradient reaching hn_l: its own state slot, plus (below the top) what the layer above sent down its input
+      float* lam_l = lam + (size_t)l * BF;
+      const float* g2 = l + 1 < L ? dinp : dout + (size_t)it * BF;
+      // the cell's backward; the GRU leaves its direct path g * z in lam_l (in place), the product with W_hh is added to it
       if (m.gru)
-        hipLaunchKernelGGL(gru_cell_bwd_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)l * B * F, l + 1 < L ? dinp : nullptr,
-                           rnn_gates[l] + (size_t)it * B * 4 * F, rnn_hp[l] + (size_t)it * B * F, d_l, dh_l, dhp_direct, B, F);
+        hipLaunchKernelGGL(gru_cell_bwd_kernel, EW_GRID(BF), 0, st, lam_l, g2, rnn_gates[l] + (size_t)it * B * 4 * F, rnn_hp[l] + (size_t)it * BF, d_l, dh_l,
+                           lam_l, B, F);
       else
-        hipLaunchKernelGGL(rnn_cell_bwd_kernel, EW_GRID((size_t)B * F), 0, st, lam + (size_t)l * B * F, l + 1 < L ? dinp : nullptr,
-                           rnn_out[l] + (size_t)it * B * F, d_l, (size_t)B * F);
-      gemm_nt(st, d_l, GF, m.rnn_wih_t[l], GF, nullptr, dinp, F, B, F, GF);               // d input  = delta_i W_ih
-      gemm_nt(st, dh_l, GF, m.rnn_whh_t[l], GF, nullptr, dhp, F, B, F, GF);              // d hidden = delta_h W_hh
-      if (m.gru) hipLaunchKernelGGL(add_kernel, EW_GRID((size_t)B * F), 0, st, dhp, dhp_direct, (size_t)B * F);   // + g * z
-      (void)hipMemcpyAsync(lam + (size_t)l * B * F, dhp, (size_t)B * F * sizeof(float), hipMemcpyDeviceToDevice, st);   // -> d evolved state
-      if (l == 0 && grad_fused) hipLaunchKernelGGL(scatter_interval_kernel, EW_GRID((size_t)B * F), 0, st, dinp, grad_fused, B, P, F, it);
+        hipLaunchKernelGGL(rnn_cell_bwd_kernel, EW_GRID(BF), 0, st, lam_l, g2, rnn_out[l] + (size_t)it * BF, d_l, BF);
+      // d input = delta_i W_ih: the layer below's second gradient, or (bottom layer) the fused features' gradient, written in place
+      if (l > 0) gemm_nt(st, d_l, GF, m.rnn_wih_t[l], GF, nullptr, dinp, F, B, F, GF);
+      else if (grad_fused) gemm_nt(st, d_l, GF, m.rnn_wih_t[l], GF, nullptr, grad_fused + (size_t)it * F, P * F, B, F, GF);
+      gemm_nt(st, dh_l, GF, m.rnn_whh_t[l], GF, nullptr, lam_l, F, B, F, GF, m.gru != 0);   // d hidden = delta_h W_hh (+ g * z) -> d evolved state
     }
     if (m.with_ode) {
       for (int j = J - 1; j >= 0; --j) {
         const float* dtp = dt + ((size_t)it * J + j) * R;
-        const size_t mstep = ((size_t)it * J + j) * S * R;
-        hipLaunchKernelGGL(step_adjoint_init_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, brow, dtp, R, F);
+        hipLaunchKernelGGL(step_adjoint_init_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, brow, dtp, act[nl] + row0(it, j, S - 1) * F,
+                           delta[nl - 1] + row0(it, j, S - 1) * F, R, F);
         for (int s = S - 1; s >= 0; --s) {
-          const size_t m0 = mstep + (size_t)s * R;
-          // K_s = tanh(.) : delta of the last Linear
-          hipLaunchKernelGGL(act_bwd_kernel, EW_GRID(RF), 0, st, lamK + (size_t)s * RF, act[nl] + m0 * F, delta[nl - 1] + m0 * F, RF, 0);
+          const size_t m0 = row0(it, j, s);
           for (int l = nl - 1; l >= 1; --l) {
             // delta_{l-1} = (delta_l W_l) * act'(saved activation): one launch
             gemm_nt(st, delta[l] + m0 * m.dims[l + 1], m.dims[l + 1], m.ode_w_t[l], m.dims[l + 1], nullptr, delta[l - 1] + m0 * m.dims[l], m.dims[l], R,
                     m.dims[l], m.dims[l + 1], false, GEPI_DACT, m.act, act[l] + m0 * m.dims[l], m.dims[l]);
           }
-          gemm_nt(st, delta[0] + m0 * m.dims[1], m.dims[1], m.ode_w_t[0], m.dims[1], nullptr, gX, F, R, F, m.dims[1]);
-          hipLaunchKernelGGL(stage_adjoint_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, gX, arow[s], dtp, R, F);
+          // gX = delta_0 W_0 with the stage's bookkeeping (and the next stage's first gradient) as the product's epilogue
+          AdjEpi e;
+          e.lam = lam; e.lamK = lamK; e.kstride = RF; e.a = arow[s]; e.dt = dtp;
+          e.Kprev = s > 0 ? act[nl] + row0(it, j, s - 1) * F : nullptr;
+          e.delta_prev = s > 0 ? delta[nl - 1] + row0(it, j, s - 1) * F : nullptr;
+          hipLaunchKernelGGL(gemm_nt_adj_kernel, dim3((F + 15) / 16, (R + 15) / 16), dim3(256), 0, st, delta[0] + m0 * m.dims[1], m.dims[1], m.ode_w_t[0],
+                             m.dims[1], R, F, m.dims[1], e);
         }
       }
     }
   }
-  if (grad_hc) (void)hipMemcpyAsync(grad_hc, lam, RF * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (grad_hc) hipLaunchKernelGGL(copy_kernel, EW_GRID(RF), 0, st, lam, grad_hc, RF);
 
   // =============================== 3. weight gradients ===============================
   if (m.with_ode) {
-    for (int l = 0; l < nl; ++l) {
-      if (g.ode_w[l]) gemm_tn(st, delta[l], m.dims[l + 1], act[l], m.dims[l], g.ode_w[l], m.dims[l], (int)M, m.dims[l + 1], m.dims[l]);
-      if (g.ode_b[l]) launch_colsum(st, delta[l], g.ode_b[l], (int)M, m.dims[l + 1]);
-    }
+    for (int l = 0; l < nl; ++l)
+      wgrad_bias(st, delta[l], m.dims[l + 1], act[l], m.dims[l], g.ode_w[l], m.dims[l], g.ode_b[l], (int)M, m.dims[l + 1], m.dims[l]);
   }
   for (int l = 0; l < L; ++l) {
-    if (g.rnn_wih[l]) gemm_tn(st, rnn_delta[l], GF, rnn_in[l], F, g.rnn_wih[l], F, (int)MB, GF, F);
-    if (g.rnn_whh[l]) gemm_tn(st, rnn_delta_h[l], GF, rnn_hp[l], F, g.rnn_whh[l], F, (int)MB, GF, F);
-    if (g.rnn_bih[l]) launch_colsum(st, rnn_delta[l], g.rnn_bih[l], (int)MB, GF);
-    if (g.rnn_bhh[l]) launch_colsum(st, rnn_delta_h[l], g.rnn_bhh[l], (int)MB, GF);
+    wgrad_bias(st, rnn_delta[l], GF, rnn_in[l], F, g.rnn_wih[l], F, g.rnn_bih[l], (int)MB, GF, F);
+    wgrad_bias(st, rnn_delta_h[l], GF, rnn_hp[l], F, g.rnn_whh[l], F, g.rnn_bhh[l], (int)MB, GF, F);
   }
-  if (g.reg_w0) gemm_tn(st, dhid, 128, rnn_out[L - 1], F, g.reg_w0, F, (int)MB, 128, F);
-  if (g.reg_b0) launch_colsum(st, dhid, g.reg_b0, (int)MB, 128);
-  if (g.reg_w2) gemm_tn(st, dpo, 6, hid, 128, g.reg_w2, 128, (int)MB, 6, 128);
-  if (g.reg_b2) launch_colsum(st, dpo, g.reg_b2, (int)MB, 6);
+  wgrad_bias(st, dhid, 128, rnn_out[L - 1], F, g.reg_w0, F, g.reg_b0, (int)MB, 128, F);
+  wgrad_bias(st, dpo, 6, hid, 128, g.reg_w2, 128, g.reg_b2, (int)MB, 6, 128);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
 
@@ -554,8 +701,7 @@ int train_fuse_bwd(int soft, const float* W, const float* W_t, const float* bias
   gemm_nt(st, c, F, W, F, bias, w, F, P, F, F);                       // w = c W^T + b
   hipLaunchKernelGGL(soft_gate_bwd_kernel, EW_GRID(n), 0, st, g_fused, c, w, gw, gc, n);
   gemm_nt(st, gw, F, W_t, F, nullptr, gc, F, P, F, F, true);           // gc += gw W   (W_t rows = columns of W)
-  if (g_W) gemm_tn(st, gw, F, c, F, g_W, F, P, F, F);                  // g_W[n][k] = sum_m gw[m][n] c[m][k]
-  if (g_b) launch_colsum(st, gw, g_b, P, F);
+  wgrad_bias(st, gw, F, c, F, g_W, F, g_b, P, F, F);                   // g_W[n][k] = sum_m gw[m][n] c[m][k];  g_b = column sums of gw
   hipLaunchKernelGGL(split_rows_kernel, EW_GRID(n), 0, st, gc, g_fv, nv, g_fi, ni, (size_t)P);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
@@ -580,11 +726,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 // out[0] = total L2 norm, out[1] = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
-__global__ void clip_coef_kernel(const double* __restrict__ partial, int n_partial, float max_norm, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n_partial; ++i) s += partial[i];
-    const float norm = (float)sqrt(s);
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ partial, int n_partial, float max_norm, float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[i];   // fixed shares, fixed tree: deterministic
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0]);
     out[0] = norm;
     out[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
   }
@@ -592,7 +745,7 @@ __global__ void clip_coef_kernel(const double* __restrict__ partial, int n_parti
 int train_grad_clip(const float* const* grads, const size_t* numel, int n, float max_norm, double* partial_ws, float* out2, hipStream_t st) {
   for (int t = 0; t < n; ++t)
     hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, grads[t], numel[t], partial_ws + (size_t)t * NORM_BLOCKS);
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, st, partial_ws, n * NORM_BLOCKS, max_norm, out2);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, partial_ws, n * NORM_BLOCKS, max_norm, out2);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
 size_t train_grad_clip_workspace_doubles(int n) { return (size_t)n * NORM_BLOCKS; }
@@ -853,8 +1006,7 @@ int train_imu_bwd(const ImuTrain& m, float* ws, const float* imu, int B, int T, 
   }
   hipLaunchKernelGGL(rows_to_ct_kernel, EW_GRID(rows * 256), 0, st, x[3], flat, (size_t)P, 256);
   // ---- proj backward
-  if (g.proj_w) gemm_tn(st, g_fi, NF, flat, 2816, g.proj_w, 2816, P, NF, 2816);
-  if (g.proj_b) launch_colsum(st, g_fi, g.proj_b, P, NF);
+  wgrad_bias(st, g_fi, NF, flat, 2816, g.proj_w, 2816, g.proj_b, P, NF, 2816);
   relayout_transpose(m.proj_w, projT, NF, 2816, st);                                   // [NF][2816] -> [2816][NF]
   gemm_nt(st, g_fi, NF, projT, NF, nullptr, gflat, 2816, P, 2816, NF);                  // g_flat = g_fi W
   hipLaunchKernelGGL(ct_to_rows_kernel, EW_GRID(rows * 256), 0, st, gflat, gy, (size_t)P, 256);
@@ -922,7 +1074,6 @@ __global__ void bn_train_rows_bwd2_kernel(const float* __restrict__ dz, const fl
     D[i] = gamma[ch] * invstd[ch] * (dz[i] - dH[ch] * invn - xh * dS[ch] * invn);
   }
 }
-__global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) { EW_LOOP(i, n) b[i] = a[i]; }
 
 size_t train_imu_train_workspace_floats(int P) { return train_imu_workspace_floats(P) + 2048; }
 
@@ -987,8 +1138,7 @@ int train_imu_bwd_train(const ImuTrain& m, const ImuTrainMode& tm, float* ws, co
   int rc = imu_train_forward(m, tm, false, x, c, xcol, mean, invstd, imu, B, T, st);   // same masks, same statistics; running stats untouched
   if (rc) return rc;
   hipLaunchKernelGGL(rows_to_ct_kernel, EW_GRID(rows * 256), 0, st, x[3], flat, (size_t)P, 256);
-  if (g.proj_w) gemm_tn(st, g_fi, NF, flat, 2816, g.proj_w, 2816, P, NF, 2816);
-  if (g.proj_b) launch_colsum(st, g_fi, g.proj_b, P, NF);
+  wgrad_bias(st, g_fi, NF, flat, 2816, g.proj_w, 2816, g.proj_b, P, NF, 2816);
   relayout_transpose(m.proj_w, projT, NF, 2816, st);
   gemm_nt(st, g_fi, NF, projT, NF, nullptr, gflat, 2816, P, 2816, NF);
   hipLaunchKernelGGL(ct_to_rows_kernel, EW_GRID(rows * 256), 0, st, gflat, gy, (size_t)P, 256);
@@ -1078,10 +1228,8 @@ int train_regressor_bwd(const float* seq, int F, const float* w0, const float* w
   hipLaunchKernelGGL(leaky_kernel, EW_GRID((size_t)M * 128), 0, st, hid, (size_t)M * 128, 0.1f);
   hipLaunchKernelGGL(reg2_bwd_kernel, EW_GRID((size_t)M * 128), 0, st, g_poses, w2, hid, dhid, M);
   if (g_seq) gemm_nt(st, dhid, 128, w0_t, 128, nullptr, g_seq, F, M, F, 128);
-  if (g_w0) gemm_tn(st, dhid, 128, seq, F, g_w0, F, M, 128, F);
-  if (g_b0) launch_colsum(st, dhid, g_b0, M, 128);
-  if (g_w2) gemm_tn(st, g_poses, 6, hid, 128, g_w2, 128, M, 6, 128);
-  if (g_b2) launch_colsum(st, g_poses, g_b2, M, 6);
+  wgrad_bias(st, dhid, 128, seq, F, g_w0, F, g_b0, M, 128, F);
+  wgrad_bias(st, g_poses, 6, hid, 128, g_w2, 128, g_b2, M, 6, 128);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
 void leaky_inplace(float* x, size_t n, float slope, hipStream_t st) { hipLaunchKernelGGL(leaky_kernel, EW_GRID(n), 0, st, x, n, slope); }
@@ -1099,8 +1247,7 @@ int train_fuse_hard_bwd(const float* W, const float* W_t, const float* bias, flo
   gemm_nt(st, cat, F, W, F, bias, logits, 2 * F, P, 2 * F, F);
   launch_hard_mask_bwd(g_fused, cat, logits, g_cat, g_logits, n, seed, call, st);
   gemm_nt(st, g_logits, 2 * F, W_t, 2 * F, nullptr, g_cat, F, P, F, 2 * F, true);   // g_cat += g_logits W
-  if (g_W) gemm_tn(st, g_logits, 2 * F, cat, F, g_W, F, P, 2 * F, F);
-  if (g_b) launch_colsum(st, g_logits, g_b, P, 2 * F);
+  wgrad_bias(st, g_logits, 2 * F, cat, F, g_W, F, g_b, P, 2 * F, F);
   hipLaunchKernelGGL(split_rows_kernel, EW_GRID(n), 0, st, g_cat, g_fv, nv, g_fi, ni, (size_t)P);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }

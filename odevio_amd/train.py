@@ -56,6 +56,11 @@ def imu_param_names():
     return names + ["Inertial_net.proj.weight", "Inertial_net.proj.bias"]
 
 
+def _versions(params):
+    """What changes when a parameter is written to (in place or replaced): the identity of a forward's weights."""
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
 def _tensor_array(names, tensors):
     arr = (_lib.OdevioTensor * len(tensors))()
     for i, (n, t) in enumerate(zip(names, tensors)):
@@ -106,8 +111,21 @@ class _OdeRnnFunction(torch.autograd.Function):
         L = model.opt.rnn_num_layers
         poses = torch.empty(B, P, 6, device=fused.device, dtype=torch.float32)
         h_T = torch.empty(L, B, F, device=fused.device, dtype=torch.float32)
-        _lib.check(model._lib.odevio_ode_rnn_fwd(model._plan, fused.data_ptr(), ts.data_ptr(), None if hcd is None else hcd.data_ptr(),
-                                                 B, P, poses.data_ptr(), h_T.data_ptr(), None, model._stream()))
+        # the log of this forward's steps, kept for backward() the way autograd keeps saved tensors: the training step then runs the
+        # persistent kernel once (without it odevio_ode_rnn_bwd runs the forward again to write the same log)
+        n_tape = ctypes.c_int64(0)
+        _lib.check(model._lib.odevio_ode_rnn_tape_floats(model._plan, B, P, ctypes.byref(n_tape)))
+        ctx.tape = None
+        hcp = None if hcd is None else hcd.data_ptr()
+        if n_tape.value > 0 and any(ctx.needs_input_grad):
+            ctx.tape = torch.empty(n_tape.value, device=fused.device, dtype=torch.float32)
+            ctx.tape_weights = _versions(params)
+            _lib.check(model._lib.odevio_ode_rnn_fwd_taped(model._plan, fused.data_ptr(), ts.data_ptr(), hcp, B, P, poses.data_ptr(),
+                                                           h_T.data_ptr(), ctx.tape.data_ptr(), n_tape.value, model._stream()))
+        else:
+            _lib.check(model._lib.odevio_ode_rnn_fwd(model._plan, fused.data_ptr(), ts.data_ptr(), hcp, B, P, poses.data_ptr(), h_T.data_ptr(),
+                                                     None, model._stream()))
+        ctx.params = params
         ctx.model, ctx.names, ctx.has_hc = model, names, hc is not None
         ctx.save_for_backward(fused, ts, *([hcd] if hcd is not None else []))
         ctx.param_shapes = [tuple(p.shape) for p in params]
@@ -129,10 +147,14 @@ class _OdeRnnFunction(torch.autograd.Function):
         for i, (n, g) in enumerate(zip(ctx.names, grads)):
             arr[i].name, arr[i].data, arr[i].numel = n.encode(), g.data_ptr(), g.numel()
         model._ensure_plan()
-        _lib.check(model._lib.odevio_ode_rnn_bwd(
-            model._plan, fused.data_ptr(), ts.data_ptr(), None if hc is None else hc.data_ptr(), B, P, g_poses.data_ptr(),
-            None if g_hT is None else g_hT.data_ptr(), g_fused.data_ptr(), None if g_hc is None else g_hc.data_ptr(),
-            arr, len(grads), model._stream()))
+        common = (model._plan, fused.data_ptr(), ts.data_ptr(), None if hc is None else hc.data_ptr(), B, P, g_poses.data_ptr(),
+                  None if g_hT is None else g_hT.data_ptr(), g_fused.data_ptr(), None if g_hc is None else g_hc.data_ptr(), arr, len(grads))
+        # (a tape is only the log of THESE weights' forward: parameters changed in between -> the plain backward writes a fresh one)
+        if ctx.tape is not None and ctx.tape_weights == _versions(ctx.params):
+            _lib.check(model._lib.odevio_ode_rnn_bwd_taped(*common, ctx.tape.data_ptr(), ctx.tape.numel(), model._stream()))
+        else:
+            _lib.check(model._lib.odevio_ode_rnn_bwd(*common, model._stream()))
+        ctx.tape = None
         return (None, None, g_fused, None, g_hc, *grads)
 
 

@@ -60,6 +60,12 @@ int main(void) {
   EXPECT(odevio_cde_bwd(NULL, x, 1, 2, NULL, 1, NULL, x, NULL, x, NULL, NULL, 0, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_debug_dropout(0, 0, 1.5f, 4, x, NULL) == ODEVIO_ERR_BAD_ARG);     /* p must be < 1 */
   EXPECT(odevio_sgd_step(x, x, NULL, 4, 1e-4f, 0.9f, 0.0f, 1, NULL, NULL) == ODEVIO_ERR_BAD_ARG);   /* momentum needs its buffer */
+  {
+    int64_t n = -1;
+    EXPECT(odevio_ode_rnn_tape_floats(NULL, 1, 1, &n) == ODEVIO_ERR_BAD_ARG);
+    EXPECT(odevio_ode_rnn_fwd_taped(NULL, x, x, NULL, 1, 1, x, x, x, 4, NULL) == ODEVIO_ERR_BAD_ARG);
+    EXPECT(odevio_ode_rnn_bwd_taped(NULL, x, x, NULL, 1, 1, x, NULL, NULL, NULL, NULL, 0, NULL, 0, NULL) == ODEVIO_ERR_BAD_ARG);
+  }
   EXPECT(odevio_resize_u8(NULL, 1, 4, 4, NULL, 2, 2, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   odevio_plan_destroy(NULL);
   /* resize tables: KITTI width and height, an upscale, a degenerate 1-pixel axis; capacity checked */

@@ -111,6 +111,61 @@ def test_adaptive_solver_backward_replays_the_accepted_steps(cfg):
     assert not bad, f"gradients off by more than {GTOL}: {bad}"
 
 
+@pytest.mark.parametrize("cfg", [dict(ode_solver="rk4", ode_substeps=2), dict(ode_solver="dopri5", ode_rnn_type="gru")])
+def test_taped_backward_equals_the_plain_one_and_the_step_by_step_tape(cfg, monkeypatch):
+    """Three routes to the same gradients: (a) the autograd function (odevio_ode_rnn_fwd_taped keeps the forward's log, _bwd_taped reads
+    it: the persistent kernel runs once per step), (b) the plain pair (the backward runs the forward again to write the same log) -
+    the same arithmetic on the same log, so bit-equal - and (c) ODEVIO_TAPE_IN_ORDER=1: no logged states, the tape walks the steps in
+    order from its own recomputed states (the route of windows whose states would not fit) - equal to rounding."""
+    import ctypes
+    from odevio_amd import _lib
+    opt = default_opt(img_h=64, img_w=128, **cfg)
+    model, _ = make_model(opt, seed=74)
+    B, P, L, F = 5, 4, opt.rnn_num_layers, 768
+    g = torch.Generator().manual_seed(8)
+    fused = torch.randn(B, P, F, generator=g).cuda()
+    ts = synth.timestamps(B, P + 1, drop=0.4, seed=5, absolute=True).cuda()
+    hc = (torch.randn(L, B, F, generator=g) * 0.3).cuda()
+    gp = (torch.randn(B, P, 6, generator=g) * 0.1).cuda()
+    ghT = (torch.randn(L, B, F, generator=g) * 0.01).cuda()
+    names = train.pose_param_names(opt)
+    params = dict(model.named_parameters())
+    model._ensure_plan()
+
+    def run(route):
+        out = {"fused": torch.empty_like(fused), "hc": torch.empty_like(hc)}
+        grads = [torch.empty_like(params[n]) for n in names]
+        arr = train._tensor_array(names, grads)
+        poses, h_T = torch.empty(B, P, 6, device="cuda"), torch.empty(L, B, F, device="cuda")
+        common = (model._plan, fused.data_ptr(), ts.data_ptr(), hc.data_ptr(), B, P, gp.data_ptr(), ghT.data_ptr(), out["fused"].data_ptr(),
+                  out["hc"].data_ptr(), arr, len(grads))
+        if route == "taped":
+            n = ctypes.c_int64(0)
+            _lib.check(model._lib.odevio_ode_rnn_tape_floats(model._plan, B, P, ctypes.byref(n)))
+            assert n.value > 0
+            tape = torch.empty(n.value, device="cuda")
+            _lib.check(model._lib.odevio_ode_rnn_fwd_taped(model._plan, fused.data_ptr(), ts.data_ptr(), hc.data_ptr(), B, P, poses.data_ptr(),
+                                                           h_T.data_ptr(), tape.data_ptr(), n.value, model._stream()))
+            _lib.check(model._lib.odevio_ode_rnn_bwd_taped(*common, tape.data_ptr(), n.value, model._stream()))
+            # a tape of another size is refused
+            assert model._lib.odevio_ode_rnn_bwd_taped(*common, tape.data_ptr(), n.value - 4, model._stream()) == _lib.ERR_BAD_ARG
+        else:
+            _lib.check(model._lib.odevio_ode_rnn_bwd(*common, model._stream()))
+        model.check()
+        out.update({n_: g_ for n_, g_ in zip(names, grads)})
+        return out
+
+    a, b = run("taped"), run("plain")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    monkeypatch.setenv("ODEVIO_TAPE_IN_ORDER", "1")
+    c = run("plain")
+    monkeypatch.delenv("ODEVIO_TAPE_IN_ORDER")
+    for k in a:
+        assert oc.rel_err(c[k], a[k]) < 2e-5, (k, oc.rel_err(c[k], a[k]))
+    assert any(not torch.equal(a[k], c[k]) for k in a)     # (the two tapes really are different routes)
+
+
 def test_euler_backward_replays_every_dt0_step():
     """euler under torchode's controller (PoseODERNN.py:125-137) has no error estimate: every dt0 = 1e-4 step is accepted until the
     interval's end (the last one clipped) - a thousand steps per 0.1 s.  The backward replays them like any logged step sequence; short
