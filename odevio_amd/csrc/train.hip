@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -69,10 +70,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   // MFMA A operand = W rows (D rows = output columns n), B operand = A rows (D columns = m)
   const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * q;
   const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // A wave's k-steps (16 * wave, += 64) eight at a time: the sixteen 16-byte loads of a batch are issued before the first MFMA
-  // waits on one, so a K = 512 row costs one round trip to L2, not eight in a chain (these products are latency, not bandwidth:
-  // 7.5 us -> see profiles/r03_train_step.txt).  Same products in the same order as a one-step loop.
+  // waits on one, so a K = 512 row costs one round trip to L2, not eight in a chain; and FOUR accumulators (one per k of a lane's
+  // float4), because these products are latency, not bandwidth: the fp32 MFMA's result is ready ~40 ns after issue, and 32 of
+  // them chained on one accumulator were 1.2 us of a 4 us workgroup (tools/probes/skinny_gemm.hip).
+  f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   for (int k0 = 16 * wave; k0 < K; k0 += 512) {
     f32x4 wv[8], av[8];
 #pragma unroll
@@ -89,8 +91,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], av[u][j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], av[u][j], acc4[j], 0, 0, 0);
   }
+  const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];   // [n local][m local]
   __syncthreads();
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   const bool ones = (int)blockIdx.x * 16 >= K;   // the bias column
   const int k0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
   const int nn = min(n0 + r, N - 1), kk = min(k0 + r, K - 1);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // four chains (see gemm_nt_kernel)
   // contraction over rows m: MFMA j of a 16-row step uses rows m = 16 s + 4 q + j; four steps' loads are issued together
   for (int mb = 16 * wave; mb < M; mb += 256) {
     float dv[4][4], av[4][4];
@@ -135,8 +138,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][j], av[u][j], acc, 0, 0, 0);   // D rows = n, D columns = k
+      for (int j = 0; j < 4; ++j) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][j], av[u][j], acc4[j], 0, 0, 0);   // D rows = n, D columns = k
   }
+  const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];   // [n local][k local]
   __syncthreads();
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(256) void gemm_nt_adj_kernel(const float* __restric
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
   const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * q;
   const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // as in gemm_nt_kernel
   for (int k0 = 16 * wave; k0 < K; k0 += 512) {
     f32x4 wv[8], av[8];
 #pragma unroll
@@ -442,8 +446,9 @@ __global__ __launch_bounds__(256) void gemm_nt_adj_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], av[u][j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], av[u][j], acc4[j], 0, 0, 0);
   }
+  const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
 #pragma unroll
   for (int x = 0; x < 4; ++x) red[wave][4 * q + x][r] = acc[x];
   __syncthreads();
