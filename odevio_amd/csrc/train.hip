@@ -60,27 +60,27 @@ __device__ __forceinline__ float tr_act_grad(float a, int act) {
 //   EPI_ACT: out = act(sum + bias)  - the ODEFunc layer itself;   EPI_DACT: out = sum * act'(aux[m][n]) - the layer's adjoint, aux = the
 //   activation's saved OUTPUT (what the tape keeps).  Same arithmetic, in the same order, as the separate element-wise kernels.
 enum GemmEpi { GEPI_NONE = 0, GEPI_ACT = 1, GEPI_DACT = 2 };
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                                      const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
-                                                      int accumulate, int epi, int act, const float* __restrict__ aux, int ldaux) {
-  __shared__ float red[4][16][17];
+
+// The 16 x 16 tile of A W^T both NT kernels compute: returns element (n0 + tid / 16, m0 + tid % 16).
+// A wave's k-steps (16 * wave, += 64) U at a time: the 2 U 16-byte loads of a batch are issued before the first MFMA waits on one,
+// so a row of K <= 64 U costs ONE round trip to memory, not U in a chain (U = 8 for K <= 512, 16 above); and FOUR accumulators (one
+// per k of a lane's float4), because these products are latency, not bandwidth: the fp32 MFMA's result is ready ~40 ns after issue,
+// and 32 of them chained on one accumulator were 1.2 us of a 4 us workgroup (tools/probes/skinny_gemm.hip).
+// K % 4 == 0: a lane's four consecutive k are inside K or all outside (a tail adds zeros); the ADDRESS is clamped and the VALUE
+// selected, so that no load sits behind a branch.
+template <int U>
+__device__ __forceinline__ float nt_tile(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int M, int N, int K, int m0, int n0,
+                                         float (*red)[16][17]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
   // MFMA A operand = W rows (D rows = output columns n), B operand = A rows (D columns = m)
   const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * q;
   const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
-  // A wave's k-steps (16 * wave, += 64) eight at a time: the sixteen 16-byte loads of a batch are issued before the first MFMA
-  // waits on one, so a K = 512 row costs one round trip to L2, not eight in a chain; and FOUR accumulators (one per k of a lane's
-  // float4), because these products are latency, not bandwidth: the fp32 MFMA's result is ready ~40 ns after issue, and 32 of
-  // them chained on one accumulator were 1.2 us of a 4 us workgroup (tools/probes/skinny_gemm.hip).
   f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = 16 * wave; k0 < K; k0 += 512) {
-    f32x4 wv[8], av[8];
+  for (int k0 = 16 * wave; k0 < K; k0 += 64 * U) {
+    f32x4 wv[U], av[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      // K % 4 == 0: a lane's four consecutive k are inside K or all outside (a tail adds zeros); the ADDRESS is clamped and the
-      // VALUE selected, so that no load sits behind a branch
+    for (int u = 0; u < U; ++u) {
       const int k = k0 + 64 * u + 4 * q;
       const bool in = k < K;
       const int kc = in ? k - 4 * q : 0;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
       if (!in) { wv[u] = f32x4{0.f, 0.f, 0.f, 0.f}; av[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], av[u][j], acc4[j], 0, 0, 0);
   }
@@ -98,14 +98,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];   // [n local][m local]
   __syncthreads();
   const int nl = tid >> 4, ml = tid & 15;
-  const int n = n0 + nl, m = m0 + ml;
-  if (n < N && m < M) {
-    float v = (red[0][nl][ml] + red[1][nl][ml]) + (red[2][nl][ml] + red[3][nl][ml]);
-    if (bias) v += bias[n];
+  return (red[0][nl][ml] + red[1][nl][ml]) + (red[2][nl][ml] + red[3][nl][ml]);
+}
+
+// What the epilogue reads besides the sum (bias, the saved activation, the old value when accumulating) is LOADED FIRST, under the
+// operand loads: these kernels run in chains where every operand was written by the launch before and comes from beyond the L2 - a
+// second round trip behind the product was a quarter of the launch.
+template <int U>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
+                                                      int accumulate, int epi, int act, const float* __restrict__ aux, int ldaux) {
+  __shared__ float red[4][16][17];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int n = n0 + (tid >> 4), m = m0 + (tid & 15);
+  const bool mine = n < N && m < M;
+  float* o = out + (size_t)(mine ? m : 0) * ldo + (mine ? n : 0);
+  const float bv = bias ? bias[mine ? n : 0] : 0.f;
+  const float xv = epi == GEPI_DACT ? aux[(size_t)(mine ? m : 0) * ldaux + (mine ? n : 0)] : 0.f;
+  const float ov = accumulate ? *o : 0.f;
+  float v = nt_tile<U>(A, lda, W, ldw, M, N, K, m0, n0, red);
+  if (mine) {
+    if (bias) v += bv;
     if (epi == GEPI_ACT) v = tr_act(v, act);
-    else if (epi == GEPI_DACT) v *= tr_act_grad(aux[(size_t)m * ldaux + n], act);
-    float* o = out + (size_t)m * ldo + n;
-    *o = accumulate ? *o + v : v;
+    else if (epi == GEPI_DACT) v *= tr_act_grad(xv, act);
+    *o = accumulate ? ov + v : v;
   }
 }
 
@@ -162,8 +179,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 
 static void gemm_nt(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N,
                     int K, bool accumulate = false, int epi = GEPI_NONE, int act = 0, const float* aux = nullptr, int ldaux = 0) {
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K,
-                     accumulate ? 1 : 0, epi, act, aux, ldaux);
+  if (K <= 512)
+    hipLaunchKernelGGL(gemm_nt_kernel<8>, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K,
+                       accumulate ? 1 : 0, epi, act, aux, ldaux);
+  else
+    hipLaunchKernelGGL(gemm_nt_kernel<16>, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K,
+                       accumulate ? 1 : 0, epi, act, aux, ldaux);
 }
 static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K,
                     bool accumulate = false, float* bias_out = nullptr) {
@@ -423,47 +444,31 @@ struct AdjEpi {
   const float* Kprev;    // K_{s-1} rows of this step (null at s = 0)
   float* delta_prev;     // where the stage below expects its last-Linear gradient
 };
+template <int U>
 __global__ __launch_bounds__(256) void gemm_nt_adj_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int M, int N, int K,
                                                           AdjEpi e) {
   __shared__ float red[4][16][17];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-  const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * q;
-  const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
-  f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // as in gemm_nt_kernel
-  for (int k0 = 16 * wave; k0 < K; k0 += 512) {
-    f32x4 wv[8], av[8];
+  const int n = n0 + (tid >> 4), m = m0 + (tid & 15);
+  const bool mine = n < N && m < M;
+  const size_t i = mine ? (size_t)m * N + n : 0;
+  // everything the bookkeeping reads, loaded under the product's operand loads (see gemm_nt_kernel)
+  const float lam0 = e.lam[i], dtm = e.dt[mine ? m : 0], kp = e.Kprev ? e.Kprev[i] : 0.f;
+  float lk[7];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = k0 + 64 * u + 4 * q;
-      const bool in = k < K;
-      const int kc = in ? k - 4 * q : 0;
-      wv[u] = *reinterpret_cast<const f32x4*>(wrow + kc);
-      av[u] = *reinterpret_cast<const f32x4*>(arow + kc);
-      if (!in) { wv[u] = f32x4{0.f, 0.f, 0.f, 0.f}; av[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    }
+  for (int j = 0; j < 7; ++j) lk[j] = j < e.a.n ? e.lamK[j * e.kstride + i] : 0.f;
+  const float g = nt_tile<U>(A, lda, W, ldw, M, N, K, m0, n0, red);
+  if (mine) {
+    e.lam[i] = lam0 + g;
+    float below = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], av[u][j], acc4[j], 0, 0, 0);
-  }
-  const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-#pragma unroll
-  for (int x = 0; x < 4; ++x) red[wave][4 * q + x][r] = acc[x];
-  __syncthreads();
-  const int nl = tid >> 4, ml = tid & 15;
-  const int n = n0 + nl, m = m0 + ml;
-  if (n < N && m < M) {
-    const float g = (red[0][nl][ml] + red[1][nl][ml]) + (red[2][nl][ml] + red[3][nl][ml]);
-    const size_t i = (size_t)m * N + n;
-    e.lam[i] += g;
-    for (int j = 0; j < e.a.n; ++j)
-      if (e.a.c[j] != 0.f) e.lamK[j * e.kstride + i] += e.dt[m] * e.a.c[j] * g;
-    if (e.Kprev) {
-      const float k = e.Kprev[i];
-      e.delta_prev[i] = e.lamK[(size_t)(e.a.n - 1) * e.kstride + i] * (1.f - k * k);
-    }
+    for (int j = 0; j < 7; ++j)
+      if (j < e.a.n) {
+        if (e.a.c[j] != 0.f) { lk[j] += dtm * e.a.c[j] * g; e.lamK[j * e.kstride + i] = lk[j]; }
+        if (j == e.a.n - 1) below = lk[j];
+      }
+    if (e.Kprev) e.delta_prev[i] = below * (1.f - kp * kp);
   }
 }
 
@@ -638,8 +643,12 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
           e.lam = lam; e.lamK = lamK; e.kstride = RF; e.a = arow[s]; e.dt = dtp;
           e.Kprev = s > 0 ? act[nl] + row0(it, j, s - 1) * F : nullptr;
           e.delta_prev = s > 0 ? delta[nl - 1] + row0(it, j, s - 1) * F : nullptr;
-          hipLaunchKernelGGL(gemm_nt_adj_kernel, dim3((F + 15) / 16, (R + 15) / 16), dim3(256), 0, st, delta[0] + m0 * m.dims[1], m.dims[1], m.ode_w_t[0],
-                             m.dims[1], R, F, m.dims[1], e);
+          if (m.dims[1] <= 512)
+            hipLaunchKernelGGL(gemm_nt_adj_kernel<8>, dim3((F + 15) / 16, (R + 15) / 16), dim3(256), 0, st, delta[0] + m0 * m.dims[1], m.dims[1], m.ode_w_t[0],
+                               m.dims[1], R, F, m.dims[1], e);
+          else
+            hipLaunchKernelGGL(gemm_nt_adj_kernel<16>, dim3((F + 15) / 16, (R + 15) / 16), dim3(256), 0, st, delta[0] + m0 * m.dims[1], m.dims[1], m.ode_w_t[0],
+                               m.dims[1], R, F, m.dims[1], e);
         }
       }
     }

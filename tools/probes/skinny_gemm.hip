@@ -4,11 +4,11 @@
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
-template <int MODE>   // 0 full, 1 no MFMA (sum the loads), 2 no loads (constants)
+template <int MODE, int CLONE = 0>   // 0 full, 1 no MFMA (sum the loads), 2 no loads (constants); CLONE: the same code as another kernel
 __global__ __launch_bounds__(256) void gemm_nt(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, float* __restrict__ out, int ldo,
                                                int M, int N, int K, u64* stamps) {
   __shared__ float red[4][16][17];
-  const u64 c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  const u64 c0 = __builtin_amdgcn_s_memtime() + CLONE, r0 = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
@@ -59,7 +59,28 @@ void run(const char* what, const float* A, const float* W, float* out, int M, in
   float ms; hipEventElapsedTime(&ms, e0, e1);
   u64 s[2]; hipMemcpy(s, stamps, 16, hipMemcpyDeviceToHost);
   printf("%-28s M %d N %d K %d: %.2f us per launch back to back; inside workgroup 0: %.2f us at %.2f GHz\n", what, M, N, K, ms * 1e3 / reps, s[1] * 0.01,
-         s[1] ? s[0] / (s[1] * 10.0) / 1e0 * 1e-0 / 1e0 * 0.001 * 1000 / 1000 : 0.0);
+         s[1] ? (double)s[0] / ((double)s[1] * 10.0) : 0.0);
+}
+void run_alt(const float* A, const float* W, float* out, int M, int N, int K, u64* stamps) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int reps = 2000;
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) {
+    const float* a = (i & 1) ? out : A;
+    float* o = (i & 1) ? const_cast<float*>(A) : out;
+    const dim3 g((N + 15) / 16, (M + 15) / 16);
+    const float* w = W + (size_t)(i % 8) * N * K;
+    switch (i % 4) {
+      case 0: hipLaunchKernelGGL((gemm_nt<0, 1>), g, dim3(256), 0, 0, a, K, w, K, o, N, M, N, K, stamps); break;
+      case 1: hipLaunchKernelGGL((gemm_nt<0, 2>), g, dim3(256), 0, 0, a, K, w, K, o, N, M, N, K, stamps); break;
+      case 2: hipLaunchKernelGGL((gemm_nt<0, 3>), g, dim3(256), 0, 0, a, K, w, K, o, N, M, N, K, stamps); break;
+      default: hipLaunchKernelGGL((gemm_nt<0, 4>), g, dim3(256), 0, 0, a, K, w, K, o, N, M, N, K, stamps); break;
+    }
+  }
+  hipEventRecord(e1, 0);
+  hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("four different kernels in turn, chained: %.2f us per launch\n", ms * 1e3 / reps);
 }
 int main() {
   const int M = 32, N = 512, K = 512;
@@ -70,6 +91,9 @@ int main() {
   run<1>("no MFMA", A, W, out, M, N, K, stamps, 1);
   run<2>("no loads", A, W, out, M, N, K, stamps, 1);
   run<0>("full, independent launches", A, W, out, M, N, K, stamps, 0);
+  run_alt(A, W, out, M, N, K, stamps);
+  hipMemset(A, 0x3c, (size_t)M * 1024 * 4); hipMemset(W, 0x3c, (size_t)8 * 1024 * 1024 * 4);
+  run<0>("full, nonzero data", A, W, out, M, N, K, stamps, 1);
   run<0>("full 768", A, W, out, M, 768, 512, stamps, 0);
   run<0>("full K 1024", A, W, out, M, 512, 1024, stamps, 0);
   return 0;
