@@ -25,12 +25,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/odevio.h"
 #include "common.h"
 #include "train.h"
 #include "bn_train.h"
+
+// element-wise launches: a grid-stride loop over n elements
+#define EW_GRID(n) dim3((unsigned)std::min<size_t>(((size_t)(n) + 255) / 256, 4096)), dim3(256)
+#define EW_LOOP(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); i += (size_t)gridDim.x * blockDim.x)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Skinny GEMMs on the fp32 MFMA (v_mfma_f32_16x16x4_f32: an exact fmaf chain).  One 4-wave workgroup per 16 x 16 output
@@ -177,6 +182,126 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   }
 }
 
+// The TN product for weight gradients with many rows (the tape's M = intervals x steps x stages x rows): a 64 x 64 output tile per
+// workgroup instead of 16 x 16 - the same two 16-byte loads per lane now feed SIXTEEN MFMAs (n = n0 + 4 r + e from the float4 of D,
+// k = k0 + 4 r + f from the float4 of A), where gemm_tn_kernel reads two floats per MFMA: the 512 x 512 gradient over 11,520 rows
+// took 310 us there, all of it operand traffic (1,024 workgroups each walking every row).  Rows are split over the four waves and
+// over `splits` workgroup layers; the waves combine in a fixed tree through LDS, the layers through slabs added in order
+// (deterministic).  Column sums of D (the bias gradient) come from one more column of workgroups, as in gemm_tn_kernel.
+// N, K, ldd, lda multiples of 4.
+__global__ __launch_bounds__(256) void gemm_tn64_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ A, int lda,
+                                                        float* __restrict__ out, int ldo, float* __restrict__ bias_out, int M, int N, int K,
+                                                        int rows_per_split, int ktiles) {
+  __shared__ float slot[2][64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const bool ones = (int)blockIdx.x >= ktiles;
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int m_begin = blockIdx.z * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+  const bool n_in = n0 + 4 * r < N, k_in = !ones && k0 + 4 * r < K;
+  const float* dcol = D + (n_in ? n0 + 4 * r : 0);
+  const float* acol = A + (k_in ? k0 + 4 * r : 0);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // a wave's 4-row steps: m_begin + 4 * wave, += 16; four steps' loads in flight
+  for (int mb = m_begin + 4 * wave; mb < m_end; mb += 64) {
+    f32x4 dv[4], av[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = mb + 16 * u + q;
+      const int mc = m < m_end ? m : m_begin;
+      dv[u] = *reinterpret_cast<const f32x4*>(dcol + (size_t)mc * ldd);
+      av[u] = ones ? (r == 0 ? f32x4{1.f, 0.f, 0.f, 0.f} : zero) : *reinterpret_cast<const f32x4*>(acol + (size_t)mc * lda);
+      if (m >= m_end || !n_in) dv[u] = zero;
+      if (m >= m_end || (!ones && !k_in)) av[u] = zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][e], av[u][f], acc[e][f], 0, 0, 0);
+  }
+  // ((wave 0 + wave 1) + (wave 2 + wave 3)): element (e, f, reg) of lane l sits at [((e * 4 + f) * 4 + reg) * 64 + l]
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[((e * 4 + f) * 4 + g) * 64 + lane] = acc[e][f][g];
+  };
+  auto add = [&](const float* src) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[e][f][g] += src[((e * 4 + f) * 4 + g) * 64 + lane];
+  };
+  if (wave == 1) put(slot[0]);
+  if (wave == 3) put(slot[1]);
+  __syncthreads();
+  if (wave == 0) add(slot[0]);
+  if (wave == 2) add(slot[1]);
+  __syncthreads();
+  if (wave == 2) put(slot[0]);
+  __syncthreads();
+  if (wave != 0) return;
+  add(slot[0]);
+  // lane l holds output rows i = 4 (l >> 4) + g and column j = l & 15 of every 16 x 16 block: n = n0 + 4 i + e, k = k0 + 4 j + f
+  const int j = lane & 15;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + 4 * (4 * (lane >> 4) + g) + e;
+      if (n >= N) continue;
+      if (ones) {
+        if (j == 0) bias_out[(size_t)blockIdx.z * N + n] = acc[e][0][g];
+      } else if (k0 + 4 * j < K) {
+        *reinterpret_cast<f32x4*>(out + ((size_t)blockIdx.z * N + n) * ldo + k0 + 4 * j) = f32x4{acc[e][0][g], acc[e][1][g], acc[e][2][g], acc[e][3][g]};
+      }
+    }
+}
+// sum of `splits` slabs [N][K] (ld K) in slab order -> out [N][K] (ldo); the same for the bias rows [splits][N]
+__global__ void tn64_combine_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial, float* __restrict__ out, int ldo,
+                                    float* __restrict__ bias_out, int N, int K, int splits, int accumulate) {
+  EW_LOOP(i, (size_t)N * (K + 1)) {
+    const int n = (int)(i / (K + 1)), k = (int)(i - (size_t)n * (K + 1));
+    if (k == K) {
+      if (!bias_out) continue;
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += bias_partial[(size_t)z * N + n];
+      bias_out[n] = accumulate ? bias_out[n] + s : s;
+    } else {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += partial[((size_t)z * N + n) * K + k];
+      float* o = out + (size_t)n * ldo + k;
+      *o = accumulate ? *o + s : s;
+    }
+  }
+}
+// scratch of the split form: one buffer per device, grown on demand (allocation is rare and synchronous; its users are ordered by their stream)
+static float* tn64_scratch(size_t floats) {
+  static std::mutex mu;
+  static float* buf[16] = {};
+  static size_t cap[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cap[dev] < floats) {
+    if (buf[dev]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[dev]); buf[dev] = nullptr; cap[dev] = 0; }
+    if (hipMalloc((void**)&buf[dev], floats * sizeof(float)) != hipSuccess) return nullptr;
+    cap[dev] = floats;
+  }
+  return buf[dev];
+}
+
 static void gemm_nt(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N,
                     int K, bool accumulate = false, int epi = GEPI_NONE, int act = 0, const float* aux = nullptr, int ldaux = 0) {
   if (K <= 512)
@@ -188,6 +313,25 @@ static void gemm_nt(hipStream_t st, const float* A, int lda, const float* W, int
 }
 static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K,
                     bool accumulate = false, float* bias_out = nullptr) {
+  // many rows and an output of at least a few 64 x 64 tiles: the wide-tile kernel (split over rows to fill the chip)
+  if (M >= 512 && N >= 64 && K >= 64 && N % 4 == 0 && K % 4 == 0 && ldd % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && getenv("ODEVIO_TN_NARROW") == nullptr) {
+    const int ktiles = (K + 63) / 64, ntiles = (N + 63) / 64;
+    int splits = std::max(1, std::min({1024 / (ktiles * ntiles), M / 256, 64}));
+    const int rows = ((M + splits - 1) / splits + 15) / 16 * 16;
+    splits = (M + rows - 1) / rows;
+    if (splits == 1 && !accumulate) {
+      hipLaunchKernelGGL(gemm_tn64_kernel, dim3(ktiles + (bias_out ? 1 : 0), ntiles, 1), dim3(256), 0, st, D, ldd, A, lda, out, ldo, bias_out, M, N, K, rows, ktiles);
+      return;
+    }
+    float* scratch = tn64_scratch((size_t)splits * N * (K + 1));
+    if (scratch) {
+      float* bias_partial = scratch + (size_t)splits * N * K;
+      hipLaunchKernelGGL(gemm_tn64_kernel, dim3(ktiles + (bias_out ? 1 : 0), ntiles, splits), dim3(256), 0, st, D, ldd, A, lda, scratch, K, bias_partial, M, N, K,
+                         rows, ktiles);
+      hipLaunchKernelGGL(tn64_combine_kernel, EW_GRID((size_t)N * (K + 1)), 0, st, scratch, bias_partial, out, ldo, bias_out, N, K, splits, accumulate ? 1 : 0);
+      return;
+    }
+  }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((K + 15) / 16 + (bias_out ? 1 : 0), (N + 15) / 16), dim3(256), 0, st, D, ldd, A, lda, out, ldo, M, N, K,
                      accumulate ? 1 : 0, bias_out);
 }
@@ -195,8 +339,6 @@ static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int
 // ---------------------------------------------------------------------------------------------------------------------
 // element-wise kernels
 // ---------------------------------------------------------------------------------------------------------------------
-#define EW_GRID(n) dim3((unsigned)std::min<size_t>(((size_t)(n) + 255) / 256, 4096)), dim3(256)
-#define EW_LOOP(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); i += (size_t)gridDim.x * blockDim.x)
 
 __global__ void act_kernel(float* x, size_t n, int act) { EW_LOOP(i, n) x[i] = tr_act(x[i], act); }
 __global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) { EW_LOOP(i, n) b[i] = a[i]; }
