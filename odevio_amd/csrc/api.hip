@@ -141,12 +141,14 @@ struct odevio_plan {
   int nlin = 0;
   int dims[INTEG_MAX_LIN + 1] = {};
   float* ode_w[INTEG_MAX_LIN] = {};
+  float* ode_wT[INTEG_MAX_LIN] = {};   // the transposes in the same member-slice layout (integrator_adj_kernel: the backward's reverse sweep)
   float* ode_b[INTEG_MAX_LIN] = {};
   float* rnn_w[INTEG_MAX_L] = {};
   float* rnn_b[INTEG_MAX_L] = {};
   int rnn_vcols = 1;
   unsigned long long* xbuf = nullptr;
   int xstride = 0;
+  IntegAdjArgs adj_base;               // what every launch of the adjoint twin shares (filled by fill_train_model)
   int* status = nullptr;
   // status words copied to pinned host memory behind every forward (no host synchronisation): the next API call that
   // finds the copy complete reports a failure of the previous forward instead of computing on garbage
@@ -468,6 +470,14 @@ static int load_pose_net(odevio_plan* p, WeightTable& wt, hipStream_t st) {
         shard_columns(w, N, {K}, t);
       }
       PN(upload(p, &p->ode_w[l], t, st));
+      {
+        // W^T as a layer of the reverse chain: Ki outputs (this Linear's inputs), Ni inputs, zero-padded like the forward's
+        std::vector<float> wtp((size_t)Ki * Ni, 0.f);
+        for (int n = 0; n < N; ++n)
+          for (int k = 0; k < K; ++k) wtp[(size_t)k * Ni + n] = w[(size_t)n * K + k];
+        shard_columns(wtp, Ki, {Ni}, t);
+        PN(upload(p, &p->ode_wT[l], t, st));
+      }
       {
         float *pw = const_cast<float*>(p->train.ode_w[l]), *pwt = const_cast<float*>(p->train.ode_w_t[l]);
         PN(upload(p, &pw, w, st));
@@ -1980,7 +1990,7 @@ static int fill_train_model(odevio_plan* p, TrainModel& m) {
   for (int l = 0; l <= p->nlin; ++l) m.dims[l] = p->dims_real[l];
   for (int l = 0; l < p->nlin; ++l) m.ode_b[l] = p->ode_b[l];
   m.reg_w0 = p->reg_w0; m.reg_b0 = p->reg_b0; m.reg_w2 = p->reg_w2; m.reg_b2 = p->reg_b2;
-  m.stages = 1; m.jmax = 1; m.adaptive = 0; m.dtlog = nullptr; m.dtcnt = nullptr; m.dtlog_cap = 0; m.ylog = nullptr; m.yend = nullptr;
+  m.stages = 1; m.jmax = 1; m.adaptive = 0; m.dtlog = nullptr; m.dtcnt = nullptr; m.dtlog_cap = 0; m.ylog = nullptr; m.yend = nullptr; m.adj = nullptr;
   if (m.with_ode) {
     IntegTableau t;
     fill_tableau(c.ode_solver, t);
@@ -1993,6 +2003,25 @@ static int fill_train_model(odevio_plan* p, TrainModel& m) {
     for (int i = 0; i < 8; ++i) {
       m.b[i] = i < m.stages ? t.b[i] : 0.f;
       for (int j = 0; j < 8; ++j) m.a[i][j] = (i < 7 && j < 7) ? t.a[i][j] : 0.f;
+    }
+    // the reverse sweep of an interval as ONE launch of the integrator's adjoint twin (weights resident, granule exchange) where the
+    // device holds the 256 co-resident workgroups it needs; ODEVIO_ADJOINT_LAUNCHES=1 keeps one launch per product (tests compare)
+    m.adj = nullptr;
+    if (p->n_cu >= INTEG_GROUPS * INTEG_MEMBERS && getenv("ODEVIO_ADJOINT_LAUNCHES") == nullptr) {
+      IntegAdjArgs& a = p->adj_base;
+      memset(&a, 0, sizeof(a));
+      a.F = p->Fi; a.Fio = p->F; a.nlin = p->nlin; a.act = c.ode_activation;
+      for (int l = 0; l <= p->nlin; ++l) { a.dims[l] = p->dims[l]; a.dims_io[l] = p->dims_real[l]; }
+      for (int l = 0; l < p->nlin; ++l) a.wT[l] = p->ode_wT[l];
+      a.S = m.stages;
+      for (int i = 0; i < 7; ++i) {
+        a.tb[i] = m.b[i];
+        for (int j = 0; j < 7; ++j) a.ta[i][j] = (i < m.stages && j < i) ? t.a[i][j] : 0.f;
+      }
+      a.xbuf = p->xbuf; a.xstride = p->xstride; a.status = p->status;
+      const char* e = getenv("ODEVIO_SAFE_HANDOFF");
+      a.allow_local = (e && e[0] == '1') ? 0 : 1;
+      m.adj = &a;
     }
   }
   return 0;
@@ -2246,6 +2275,7 @@ extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, 
       relayout_shard(w, p->ode_w[l], N, K, INTEG_MEMBERS, st);
       copy(const_cast<float*>(p->train.ode_w[l]), w, (size_t)N * K);
       relayout_transpose(w, const_cast<float*>(p->train.ode_w_t[l]), N, K, st);
+      relayout_shard(p->train.ode_w_t[l], p->ode_wT[l], K, N, INTEG_MEMBERS, st);   // (behind the transpose on the same stream)
       copy(p->ode_b[l], src(pre + ".bias", N), N);
     }
   for (int l = 0; l < p->cfg.rnn_num_layers; ++l) {

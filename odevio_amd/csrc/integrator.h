@@ -77,3 +77,36 @@ struct IntegArgs {
 };
 
 int launch_integrator(const IntegArgs& a, int rt, size_t lds_bytes, void* stream);
+
+// ---- the adjoint twin (integrator_adj_kernel): the reverse sweep of ONE interval's Runge-Kutta steps for every row, with the
+// TRANSPOSED ODEFunc weights resident in LDS / registers and the same granule exchange between layers - what the backward
+// (train.hip) otherwise does with one launch per product (S x layers per accepted step).  Per stage, last first:
+//   dl = lamK_s * (1 - K_s^2) -> [delta_l = (delta_{l+1} W_{l+1}) * act'(a_l)] for the layers, last first -> gX;  lam += gX;  lamK_j += dt a_sj gX
+// reading the saved activations from the backward's tape and writing every layer's pre-activation gradient there (the weight
+// gradients are products over the whole tape afterwards).  Rows whose interval took fewer steps carry dt = 0 for the rest:
+// zeros through the same arithmetic, no special case.
+struct IntegAdjArgs {
+  int F, Fio, nlin, act;                  // F internal (padded) state width; Fio the tape's / caller's
+  int dims[INTEG_MAX_LIN + 1];            // internal widths F, H, .., H, F
+  int dims_io[INTEG_MAX_LIN + 1];         // the tape's widths (row strides of act[l] / delta[l-1])
+  const float* wT[INTEG_MAX_LIN];         // W_l^T as a layer (inputs dims[l+1], outputs dims[l]) in the members' slice layout
+  int w_lds_off[INTEG_MAX_LIN];
+  int S;                                  // stages that carry gradient (FSAL: without the last)
+  float ta[7][7], tb[7];
+  // tape geometry: row of (stage s, interval it, step j, row r) = s * stage_rows + (it * J + j) * Rtot + r
+  int J, it, Rtot;
+  size_t stage_rows;
+  const float* tape_act[INTEG_MAX_LIN + 1];   // saved activation OUTPUTS, [l] for l = 1 .. nlin ([nlin] = K, the stage derivative)
+  float* tape_delta[INTEG_MAX_LIN];        // [l]: the gradient at the output of Linear l (pre-activation), width dims_io[l+1]
+  const float* dt;                        // [(it * J + j) * Rtot + r]
+  float* lam;                             // [Rtot][Fio] in / out: dL/d(state at the interval's end) -> dL/d(state at its start)
+  // rows of this launch (as IntegArgs)
+  int B, b_begin, b_end, G, BPG, rows_per_group;
+  unsigned long long* xbuf;
+  int xstride;
+  int* status;
+  int allow_local;
+  int lds_xin, lds_misc, lds_w;
+};
+// every chunk of rows of one interval (L RNN layers x B sequences, as run in the forward); base: everything but the rows and the LDS carve
+int launch_integrator_adj(const IntegAdjArgs& base, int L, int B, void* stream);

@@ -37,6 +37,7 @@
 //  * everything per element (bias, activation, publish, Runge-Kutta arithmetic, controller) runs on the
 //    OWNER thread of that element only: element (row r, local column cl) lives on thread cl*RT + r
 //    (at most 256 threads = waves 0..3), so the other twelve waves skip it instead of repeating it.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -775,5 +776,246 @@ int launch_integrator(const IntegArgs& a, int rt, size_t lds_bytes, void* stream
   else if (rt <= 4) e = launch_rt<4>(a, lds_bytes, st);
   else e = launch_rt<8>(a, lds_bytes, st);
   if (e) return e;
+  return (int)hipGetLastError();
+}
+
+// =====================================================================================================================
+// The adjoint twin: reverse sweep of one interval's accepted steps (IntegAdjArgs, integrator.h).  Same groups, members, owner
+// map, exchange protocol and layer products as integrator_kernel; the chain runs the ODEFunc backwards through W^T.
+// =====================================================================================================================
+// derivative of ODEFunc's hidden activation through its saved OUTPUT a (train.hip's tr_act_grad; ODEFunc.py:23-36)
+__device__ __forceinline__ float hidden_act_grad(float a, int act) {
+  switch (act) {
+    case 0: return 1.f - a * a;
+    case 1: return a > 0.f ? 1.f : 0.f;
+    case 2: return a > 0.f ? 1.f : 0.01f;
+    default: return a > 20.f ? 1.f : -expm1f(-a);
+  }
+}
+
+template <int RT>
+__global__ __launch_bounds__(INTEG_THREADS) void integrator_adj_kernel(const IntegAdjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MAXG = (RT * INTEG_KMAX + NT - 1) / NT;
+  Ctx c;
+  c.tid = threadIdx.x;
+  c.lane = c.tid & 63;
+  c.wave = c.tid >> 6;
+  const int g = blockIdx.x & (INTEG_GROUPS - 1);
+  c.cu = blockIdx.x >> 3;
+  if (g >= a.G) return;
+  c.epoch = 0;
+  c.status = a.status;
+  c.failed = false;
+  c.local = false;
+  c.xb = a.xbuf + (size_t)(2 * g) * a.xstride;
+  c.xstride = a.xstride;
+  c.t_gather = c.t_layer = c.t_rnn = c.n_gather = c.t_bar = c.t_epi = 0;
+  const int tid = c.tid, lane = c.lane, wave = c.wave, cu = c.cu;
+
+  float* xin = smem + a.lds_xin;    // [RT][KMAXp]   gathered layer input
+  float* lay = smem + a.lds_misc;   // [128][RT]     layer-product totals, out[col*RT + row]
+  float* nrm = lay + 128 * RT;      // [RT][32]      census scratch
+  float* wl = smem + a.lds_w;
+
+  const int F = a.F, Fio = a.Fio;
+  const int NCF = F / INTEG_MEMBERS;
+  const int R = a.rows_per_group;
+  const int BPG = a.BPG;
+  const int nlin = a.nlin, S = a.S;
+
+  // ---- owner role, as in the forward: thread t < NCF*RT owns state element (row = t % RT, local column = t / RT)
+  const int orow = tid % RT, ocl = tid / RT;
+  const bool owner = ocl < NCF && orow < R;
+  const int ocg = cu * NCF + (ocl < NCF ? ocl : 0);
+  int grow = 0;
+  bool row_valid = false;
+  if (orow < R) {
+    const int row_l = orow / BPG;
+    const int row_b = a.b_begin + g * BPG + (orow - row_l * BPG);
+    row_valid = row_b < a.b_end;
+    grow = row_l * a.B + row_b;
+  }
+  const bool mine_io = owner && row_valid && ocg < Fio;   // this thread's state element exists in the caller's tensors
+  float lam = mine_io ? a.lam[(size_t)grow * Fio + ocg] : 0.f;
+
+  if (a.allow_local) {   // placement census (see integrator_kernel)
+    ++c.epoch;
+    const unsigned mine = xcc_id();
+    if (tid == 0) put(buf_of(c, c.epoch) + cu, __uint_as_float(mine + 1u), c.epoch, false);
+    gather<MAXG>(c, buf_of(c, c.epoch), c.epoch, 1, INTEG_MEMBERS, INTEG_MEMBERS, nrm);
+    bool same = true;
+    for (int m = 0; m < INTEG_MEMBERS; ++m) same = same && (__float_as_uint(nrm[m]) == mine + 1u);
+    c.local = same && !c.failed;
+    __syncthreads();
+  }
+
+  // ---- resident slices of the transposed weights -> LDS; one that does not fit lives in registers (layer_reg's shape)
+  for (int l = 0; l < nlin; ++l) {
+    if (a.w_lds_off[l] < 0) continue;
+    const int n = (a.dims[l] / INTEG_MEMBERS) * pad256(a.dims[l + 1]);
+    const float* src = a.wT[l] + (size_t)cu * n;
+    float* dstw = wl + a.w_lds_off[l];
+    for (int i = tid * 4; i < n; i += NT * 4)
+      *reinterpret_cast<f32x4*>(dstw + i) = *reinterpret_cast<const f32x4*>(src + i);
+  }
+  __syncthreads();
+  int lreg = -1;
+  f32x4 wreg[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int l = 0; l < nlin; ++l)
+    if (lreg < 0 && a.w_lds_off[l] < 0 && a.dims[l] / INTEG_MEMBERS <= 16 && pad256(a.dims[l + 1]) == 512) lreg = l;
+  if (lreg >= 0) {
+    const int NC = a.dims[lreg] / INTEG_MEMBERS;
+    if (wave < NC) {
+      const float* src = a.wT[lreg] + (size_t)cu * NC * 512 + ((size_t)wave * 64 + lane) * 4;
+      wreg[0] = *reinterpret_cast<const f32x4*>(src);
+      wreg[1] = *reinterpret_cast<const f32x4*>(src + (size_t)NC * 256);
+    }
+  }
+
+  int off_ode[RT];
+
+  // the ODEFunc backwards: the owners hand in the gradient dl at the last Linear's output (tape row rb of their row) and get the
+  // gradient at the stage's input back; every layer's pre-activation gradient goes to the tape on the way
+  auto feval_T = [&](float dl, size_t rb) __attribute__((always_inline)) -> float {
+    float gx = 0.f;
+    ++c.epoch;
+    if (owner) put(buf_of(c, c.epoch) + orow * F + ocg, dl, c.epoch, c.local);
+    for (int l = nlin - 1; l >= 0; --l) {
+      const int K = a.dims[l + 1], N = a.dims[l];   // W_l^T: K inputs (the layer's outputs), N outputs (its inputs)
+      const int Kp = pad256(K);
+      const int NC = N / INTEG_MEMBERS;
+      const bool more = l > 0;
+      const bool mine = ocl < NC && orow < R;
+      const int col = cu * NC + (ocl < NC ? ocl : 0);
+      const bool mine_tape = mine && row_valid && col < a.dims_io[l];
+      // the saved activation this thread's product is scaled with: asked for before the gather, used after the product
+      float av = 0.f;
+      if (more && mine_tape) av = a.tape_act[l][rb * a.dims_io[l] + col];
+      gather<MAXG>(c, buf_of(c, c.epoch), c.epoch, R, K, Kp, xin);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) off_ode[r] = (r < R ? r : R - 1) * Kp;
+      if (a.w_lds_off[l] >= 0)
+        layer<RT>(wl + a.w_lds_off[l], NC, Kp, xin, off_ode, 0, xin, off_ode, wave, lane, lay);
+      else if (l == lreg)
+        layer_reg<RT>(wreg, NC, xin, off_ode, wave, lane, lay);
+      else
+        layer<RT>(a.wT[l] + (size_t)cu * NC * Kp, NC, Kp, xin, off_ode, 0, xin, off_ode, wave, lane, lay);
+      __syncthreads();
+      if (mine) {
+        float v = lay[tid];
+        if (more) {
+          v *= hidden_act_grad(av, a.act);
+          if (mine_tape) a.tape_delta[l - 1][rb * a.dims_io[l] + col] = v;
+          put(buf_of(c, c.epoch + 1) + orow * N + col, v, c.epoch + 1, c.local);
+        } else {
+          gx = v;
+        }
+      }
+      if (more) ++c.epoch;
+    }
+    return gx;
+  };
+
+  for (int j = a.J - 1; j >= 0 && !c.failed; --j) {
+    const size_t step_row = ((size_t)a.it * a.J + j) * a.Rtot + grow;
+    const float dtr = (orow < R && row_valid) ? a.dt[step_row] : 0.f;
+    float lk[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) lk[s] = s < S ? dtr * a.tb[s] * lam : 0.f;   // lamK_s = dt b_s lam
+    for (int s = S - 1; s >= 0; --s) {
+      if (c.failed) break;
+      const size_t rb = (size_t)s * a.stage_rows + step_row;
+      float dl = 0.f;
+      if (mine_io) {
+        const float ks = a.tape_act[nlin][rb * Fio + ocg];   // K_s = tanh(.)
+        float lks = 0.f;
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+          if (q == s) lks = lk[q];
+        dl = lks * (1.f - ks * ks);
+        a.tape_delta[nlin - 1][rb * Fio + ocg] = dl;
+      }
+      const float gx = feval_T(dl, rb);
+      if (owner) {
+        lam += gx;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          if (q < s) {
+            const float co = a.ta[s][q];
+            if (co != 0.f) lk[q] += dtr * co * gx;
+          }
+      }
+    }
+  }
+  if (mine_io && !c.failed) a.lam[(size_t)grow * Fio + ocg] = lam;
+}
+
+template <int RT>
+static int launch_adj_rt(const IntegAdjArgs& a, size_t lds_bytes, hipStream_t st) {
+  static unsigned long long attr_mask = 0;   // per device
+  static size_t checked_lds[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    const hipError_t e = once_per_device(attr_mask, [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(integrator_adj_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    });
+    if (e != hipSuccess) return (int)e;
+  }
+  const int grid = INTEG_GROUPS * INTEG_MEMBERS;
+  std::lock_guard<std::mutex> guard(launch_once_mutex());
+  if (checked_lds[dev & 63] != lds_bytes) {   // every member resident at once, or no launch (see launch_rt)
+    int per_cu = 0, n_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(integrator_adj_kernel<RT>), INTEG_THREADS, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    if ((long)per_cu * n_cu < grid) return (int)hipErrorCooperativeLaunchTooLarge;
+    checked_lds[dev & 63] = lds_bytes;
+  }
+  hipLaunchKernelGGL(integrator_adj_kernel<RT>, dim3(grid), dim3(INTEG_THREADS), lds_bytes, st, a);
+  return 0;
+}
+
+int launch_integrator_adj(const IntegAdjArgs& base, int L, int B, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipGetLastError();
+  const int bpg_max = 8 / L;  // rows per group <= 8 (the forward's chunks: api.hip run_sequence)
+  const int chunk = INTEG_GROUPS * bpg_max;
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = std::min(chunk, B - b0);
+    const int BPG = (nb + INTEG_GROUPS - 1) / INTEG_GROUPS;
+    const int R = L * BPG;
+    const int rt = R <= 2 ? 2 : (R <= 4 ? 4 : 8);
+    IntegAdjArgs a = base;
+    a.B = B; a.b_begin = b0; a.b_end = b0 + nb;
+    a.BPG = BPG; a.G = (nb + BPG - 1) / BPG; a.rows_per_group = R;
+    // LDS carve (floats), as the forward's: gathered input, product totals + census scratch, then the largest slices that fit
+    int maxdim = 256;
+    for (int l = 0; l <= a.nlin; ++l) maxdim = std::max(maxdim, (a.dims[l] + 255) & ~255);
+    int off = 0;
+    a.lds_xin = off; off += rt * maxdim;
+    a.lds_misc = off; off += 128 * rt + rt * 32;
+    off = (off + 3) & ~3;
+    a.lds_w = off;
+    int budget = (160 * 1024 - 1024) / 4 - off;
+    int order[INTEG_MAX_LIN];
+    auto slice = [&](int l) { return (a.dims[l] / INTEG_MEMBERS) * ((a.dims[l + 1] + 255) & ~255); };
+    for (int l = 0; l < a.nlin; ++l) { order[l] = l; a.w_lds_off[l] = -1; }
+    std::stable_sort(order, order + a.nlin, [&](int x, int y) { return slice(x) > slice(y); });
+    int woff = 0;
+    for (int i = 0; i < a.nlin; ++i) {
+      const int l = order[i], n = slice(l);
+      if (n <= budget) { a.w_lds_off[l] = woff; woff += n; budget -= n; }
+    }
+    const size_t lds = (size_t)(off + woff) * sizeof(float);
+    if (hipMemsetAsync(a.xbuf, 0, (size_t)INTEG_GROUPS * 2 * a.xstride * sizeof(unsigned long long), st) != hipSuccess) return (int)hipGetLastError();
+    int e;
+    if (rt <= 2) e = launch_adj_rt<2>(a, lds, st);
+    else if (rt <= 4) e = launch_adj_rt<4>(a, lds, st);
+    else e = launch_adj_rt<8>(a, lds, st);
+    if (e) return e;
+  }
   return (int)hipGetLastError();
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include "integrator.h"
 #include "philox.h"
 
 #define TRAIN_MAX_LIN 6
@@ -31,6 +32,9 @@ struct TrainModel {
   // [rows][P][F] the evolved state of each interval (+ dtcnt).  With them the tape is rebuilt in one batch over all steps.
   const float* ylog;
   const float* yend;
+  // optional: the launch-independent arguments of the integrator's adjoint twin (integrator.h); with them the reverse sweep of an
+  // interval's Runge-Kutta steps is ONE persistent launch instead of one launch per product
+  const IntegAdjArgs* adj;
 };
 
 // Where the weight gradients go (device pointers, same shapes as the reference's parameters; null = not wanted).

@@ -768,7 +768,16 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
       else if (grad_fused) gemm_nt(st, d_l, GF, m.rnn_wih_t[l], GF, nullptr, grad_fused + (size_t)it * F, P * F, B, F, GF);
       gemm_nt(st, dh_l, GF, m.rnn_whh_t[l], GF, nullptr, lam_l, F, B, F, GF, m.gru != 0);   // d hidden = delta_h W_hh (+ g * z) -> d evolved state
     }
-    if (m.with_ode) {
+    if (m.with_ode && m.adj) {
+      // all J steps of the interval, every stage and layer, in one launch per chunk of rows (integrator_adj_kernel)
+      IntegAdjArgs a = *m.adj;
+      a.J = J; a.it = it; a.Rtot = R; a.stage_rows = PJR;
+      for (int l = 1; l <= nl; ++l) a.tape_act[l] = act[l];
+      for (int l = 0; l < nl; ++l) a.tape_delta[l] = delta[l];
+      a.dt = dt; a.lam = lam;
+      const int e = launch_integrator_adj(a, L, B, st);
+      if (e) return ODEVIO_ERR_HIP;
+    } else if (m.with_ode) {
       for (int j = J - 1; j >= 0; --j) {
         const float* dtp = dt + ((size_t)it * J + j) * R;
         hipLaunchKernelGGL(step_adjoint_init_kernel, EW_GRID(RF), 0, st, lam, lamK, RF, brow, dtp, act[nl] + row0(it, j, S - 1) * F,

@@ -158,6 +158,13 @@ def test_taped_backward_equals_the_plain_one_and_the_step_by_step_tape(cfg, monk
     a, b = run("taped"), run("plain")
     for k in a:
         assert torch.equal(a[k], b[k]), k
+    # the reverse sweep of an interval as one launch of the integrator's adjoint twin (default) against one launch per product
+    monkeypatch.setenv("ODEVIO_ADJOINT_LAUNCHES", "1")
+    d = run("plain")
+    monkeypatch.delenv("ODEVIO_ADJOINT_LAUNCHES")
+    for k in a:
+        assert oc.rel_err(d[k], a[k]) < 2e-5, (k, oc.rel_err(d[k], a[k]))
+    assert any(not torch.equal(a[k], d[k]) for k in a)
     monkeypatch.setenv("ODEVIO_TAPE_IN_ORDER", "1")
     c = run("plain")
     monkeypatch.delenv("ODEVIO_TAPE_IN_ORDER")
