@@ -73,7 +73,9 @@ enum GemmEpi { GEPI_NONE = 0, GEPI_ACT = 1, GEPI_DACT = 2 };
 // and 32 of them chained on one accumulator were 1.2 us of a 4 us workgroup (tools/probes/skinny_gemm.hip).
 // K % 4 == 0: a lane's four consecutive k are inside K or all outside (a tail adds zeros); the ADDRESS is clamped and the VALUE
 // selected, so that no load sits behind a branch.
-template <int U>
+// NW waves share the k-steps of a row round robin (4, or 16 for the long rows of the RNN's 3F-wide products: 36 steps of one wave
+// were three batches in a chain).
+template <int U, int NW>
 __device__ __forceinline__ float nt_tile(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int M, int N, int K, int m0, int n0,
                                          float (*red)[16][17]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,11 +84,11 @@ __device__ __forceinline__ float nt_tile(const float* __restrict__ A, int lda, c
   const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * q;
   const float* arow = A + (size_t)min(m0 + r, M - 1) * lda + 4 * q;
   f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = 16 * wave; k0 < K; k0 += 64 * U) {
+  for (int k0 = 16 * wave; k0 < K; k0 += 16 * NW * U) {
     f32x4 wv[U], av[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = k0 + 64 * u + 4 * q;
+      const int k = k0 + 16 * NW * u + 4 * q;
       const bool in = k < K;
       const int kc = in ? k - 4 * q : 0;
       wv[u] = *reinterpret_cast<const f32x4*>(wrow + kc);
@@ -102,27 +104,31 @@ __device__ __forceinline__ float nt_tile(const float* __restrict__ A, int lda, c
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[wave][4 * q + e][r] = acc[e];   // [n local][m local]
   __syncthreads();
-  const int nl = tid >> 4, ml = tid & 15;
-  return (red[0][nl][ml] + red[1][nl][ml]) + (red[2][nl][ml] + red[3][nl][ml]);
+  const int nl = (tid >> 4) & 15, ml = tid & 15;
+  float g[NW / 4];
+#pragma unroll
+  for (int i = 0; i < NW / 4; ++i) g[i] = (red[4 * i][nl][ml] + red[4 * i + 1][nl][ml]) + (red[4 * i + 2][nl][ml] + red[4 * i + 3][nl][ml]);
+  if (NW == 4) return g[0];
+  return (g[0] + g[1 % (NW / 4)]) + (g[2 % (NW / 4)] + g[3 % (NW / 4)]);
 }
 
 // What the epilogue reads besides the sum (bias, the saved activation, the old value when accumulating) is LOADED FIRST, under the
 // operand loads: these kernels run in chains where every operand was written by the launch before and comes from beyond the L2 - a
 // second round trip behind the product was a quarter of the launch.
-template <int U>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                                      const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
-                                                      int accumulate, int epi, int act, const float* __restrict__ aux, int ldaux) {
-  __shared__ float red[4][16][17];
+template <int U, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
+                                                          int accumulate, int epi, int act, const float* __restrict__ aux, int ldaux) {
+  __shared__ float red[NW][16][17];
   const int tid = threadIdx.x;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-  const int n = n0 + (tid >> 4), m = m0 + (tid & 15);
-  const bool mine = n < N && m < M;
+  const int n = n0 + ((tid >> 4) & 15), m = m0 + (tid & 15);
+  const bool mine = tid < 256 && n < N && m < M;
   float* o = out + (size_t)(mine ? m : 0) * ldo + (mine ? n : 0);
   const float bv = bias ? bias[mine ? n : 0] : 0.f;
   const float xv = epi == GEPI_DACT ? aux[(size_t)(mine ? m : 0) * ldaux + (mine ? n : 0)] : 0.f;
   const float ov = accumulate ? *o : 0.f;
-  float v = nt_tile<U>(A, lda, W, ldw, M, N, K, m0, n0, red);
+  float v = nt_tile<U, NW>(A, lda, W, ldw, M, N, K, m0, n0, red);
   if (mine) {
     if (bias) v += bv;
     if (epi == GEPI_ACT) v = tr_act(v, act);
@@ -304,12 +310,14 @@ static float* tn64_scratch(size_t floats) {
 
 static void gemm_nt(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N,
                     int K, bool accumulate = false, int epi = GEPI_NONE, int act = 0, const float* aux = nullptr, int ldaux = 0) {
+  const dim3 grid((N + 15) / 16, (M + 15) / 16);
+  const int acc = accumulate ? 1 : 0;
   if (K <= 512)
-    hipLaunchKernelGGL(gemm_nt_kernel<8>, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K,
-                       accumulate ? 1 : 0, epi, act, aux, ldaux);
+    hipLaunchKernelGGL((gemm_nt_kernel<8, 4>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K, acc, epi, act, aux, ldaux);
+  else if (K <= 1024 || grid.x * grid.y >= 512)   // (a grid that fills the chip anyway keeps the small workgroups)
+    hipLaunchKernelGGL((gemm_nt_kernel<16, 4>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K, acc, epi, act, aux, ldaux);
   else
-    hipLaunchKernelGGL(gemm_nt_kernel<16>, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K,
-                       accumulate ? 1 : 0, epi, act, aux, ldaux);
+    hipLaunchKernelGGL((gemm_nt_kernel<16, 16>), grid, dim3(1024), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K, acc, epi, act, aux, ldaux);
 }
 static void gemm_tn(hipStream_t st, const float* D, int ldd, const float* A, int lda, float* out, int ldo, int M, int N, int K,
                     bool accumulate = false, float* bias_out = nullptr) {
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256) void gemm_nt_adj_kernel(const float* __restric
   float lk[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) lk[j] = j < e.a.n ? e.lamK[j * e.kstride + i] : 0.f;
-  const float g = nt_tile<U>(A, lda, W, ldw, M, N, K, m0, n0, red);
+  const float g = nt_tile<U, 4>(A, lda, W, ldw, M, N, K, m0, n0, red);
   if (mine) {
     e.lam[i] = lam0 + g;
     float below = 0.f;
