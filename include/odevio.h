@@ -357,9 +357,11 @@ int odevio_profile_enable(odevio_plan* plan, int32_t on);
 int odevio_profile_read(odevio_plan* plan, float* ms_out);
 
 /* Diagnostic build only (make STAMPS=1 -> libodevio_stamps.so): in-kernel phase totals of the last integrator
- * launch, in 100 MHz ticks: [0] kernel, [1] waiting in all-gathers, [2] ODEFunc layer products, [3] RNN layer
- * products, [4] number of all-gathers.  The production library leaves the words at zero. */
-int odevio_debug_stamps(odevio_plan* plan, uint64_t* out8, void* stream);
+ * launch, in shader clocks: [0] kernel, [1] waiting in all-gathers, [2] ODEFunc layer products, [3] RNN layer
+ * products, [4] number of all-gathers, [5] per-group placement bits, [6] post-product barriers, [7] owner epilogues, [8] launch
+ * to first interval, [9] vector-field evaluations, [10] error norm + controller, [11] RNN phases.  out12: TWELVE words.  The
+ * production library leaves them at zero. */
+int odevio_debug_stamps(odevio_plan* plan, uint64_t* out12, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1537,7 +1537,7 @@ static int integ_common(odevio_plan* p, IntegArgs& a, int rt, int solver, int su
   a.nsub = is_fixed_step(solver) ? substeps : 0;
   a.atol = c.atol; a.rtol = c.rtol; a.dt0 = c.dt0; a.max_steps = c.max_steps;
   a.xbuf = p->xbuf; a.xstride = p->xstride; a.status = p->status;
-  a.dbg = (unsigned long long*)(p->status + 8);  // 8 x u64 behind the status word (diagnostic build only)
+  a.dbg = (unsigned long long*)(p->status + 8);  // 12 x u64 behind the status words (diagnostic build only)
   {
     // ODEVIO_SAFE_HANDOFF=1 keeps every group on the placement-independent write-through protocol (tests run both)
     const char* e = getenv("ODEVIO_SAFE_HANDOFF");
@@ -1720,7 +1720,7 @@ extern "C" int odevio_resize_table(int32_t in_size, int32_t out_size, int32_t* k
 
 extern "C" int odevio_debug_stamps(odevio_plan* p, uint64_t* out8, void* stream) {
   ARGCHK(p && out8, "odevio_debug_stamps: bad argument");
-  HIPCHK(hipMemcpyAsync(out8, p->status + 8, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipMemcpyAsync(out8, p->status + 8, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));   // (the 128-byte status block: 8 ints + 12 stamps)
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }

@@ -481,6 +481,8 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
     return;
   }
 
+  unsigned long long t_pro = 0, t_feval = 0, t_norm = 0, t_rnnphase = 0;   // (diagnostic build only)
+  STAMP_ADD(t_pro, t_begin);
   const int S = a.tab.stages;
   const float inv_order = -1.f / (float)a.tab.order;
   const int n_int = seq_mode ? a.P : 1;
@@ -545,7 +547,9 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
             }
             sv = y + dt * a0;
           }
+          const unsigned long long sf0 = STAMP_NOW();
           const float ko = feval(sv);
+          STAMP_ADD(t_feval, sf0);
 #pragma unroll
           for (int j = 0; j < 7; ++j)
             if (j == s) k[j] = ko;
@@ -573,6 +577,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
         const float y1 = y + dt * s0;
         const float er = dt * e0;
         bool accept = true;
+        const unsigned long long sn0 = STAMP_NOW();
         if (a.tab.has_err) {
           // per-row RMS of err / (atol + rtol*max(|y0|,|y1|)) over all F columns (torchode rms_norm)
           __syncthreads();  // qb free
@@ -604,6 +609,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
         } else {
           dtn = dt;
         }
+        STAMP_ADD(t_norm, sn0);
         const bool upd = accept && running;
         if (running) ++n_steps;
         if (upd) {
@@ -642,6 +648,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
 
     // ======================= RNN phase =======================
     // 1. all-gather the evolved states h~ [R][F] -> hst
+    const unsigned long long sp0 = STAMP_NOW();
     ++c.epoch;
     if (owner) put(buf_of(c, c.epoch) + orow * F + ocg, y, c.epoch, c.local);
     gather<MAXG>(c, buf_of(c, c.epoch), c.epoch, R, F, Fp, hst);
@@ -699,6 +706,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
     __syncthreads();
     if (owner) y = mv[orow * 32 + ocl];
     __syncthreads();
+    STAMP_ADD(t_rnnphase, sp0);
   }
 
 #ifdef ODEVIO_STAMPS
@@ -710,9 +718,13 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_kernel(const IntegAr
     a.dbg[4] = c.n_gather;
     a.dbg[6] = c.t_bar;
     a.dbg[7] = c.t_epi;
+    a.dbg[8] = t_pro;         // launch -> first interval (census, weights -> LDS)
+    a.dbg[9] = t_feval;       // vector-field evaluations (their gathers, products, epilogues)
+    a.dbg[10] = t_norm;       // error norm + controller (its gather included)
+    a.dbg[11] = t_rnnphase;   // RNN phases (their gathers and products included)
   }
 #else
-  (void)t_begin;
+  (void)t_begin; (void)t_pro; (void)t_feval; (void)t_norm; (void)t_rnnphase;
 #endif
   // ---- outputs
   if (owner && row_valid && !c.failed) {

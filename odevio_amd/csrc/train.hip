@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -308,10 +309,110 @@ static float* tn64_scratch(size_t floats) {
   return buf[dev];
 }
 
+// The NT product for MANY rows (the batched tape: every step of the window at once; the encoders' row matrices): a 64 x 64 output tile
+// per workgroup - a k-step's eight 16-byte loads per lane feed 64 MFMAs, where the 16 x 16 tile re-reads its W rows once per 16 rows
+// of A (120 times for the tape's 1,920 rows).  The four waves take the k-steps round robin and combine in a fixed tree through LDS.
+// Epilogues: bias, EPI_ACT, accumulate.  N, ldo multiples of 4.
+__global__ __launch_bounds__(256) void gemm_nt64_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int N, int K,
+                                                        int accumulate, int epi, int act) {
+  __shared__ float slot[2][64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  const float* wrow[4];
+  const float* arow[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    wrow[b] = W + (size_t)min(n0 + 16 * b + r, N - 1) * ldw + 4 * q;
+    arow[b] = A + (size_t)min(m0 + 16 * b + r, M - 1) * lda + 4 * q;
+  }
+  f32x4 acc[4][4];   // [m block][n block]
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 16 * wave; k0 < K; k0 += 128) {   // two k-steps of this wave per batch
+    f32x4 wv[2][4], av[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = k0 + 64 * u + 4 * q;
+      const bool in = k < K;
+      const int kc = in ? k - 4 * q : 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        wv[u][b] = *reinterpret_cast<const f32x4*>(wrow[b] + kc);
+        av[u][b] = *reinterpret_cast<const f32x4*>(arow[b] + kc);
+        if (!in) { wv[u][b] = f32x4{0.f, 0.f, 0.f, 0.f}; av[u][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][nb][j], av[u][mb][j], acc[mb][nb], 0, 0, 0);
+  }
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[((mb * 4 + nb) * 4 + g) * 64 + lane] = acc[mb][nb][g];
+  };
+  auto add = [&](const float* src) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[mb][nb][g] += src[((mb * 4 + nb) * 4 + g) * 64 + lane];
+  };
+  if (wave == 1) put(slot[0]);
+  if (wave == 3) put(slot[1]);
+  __syncthreads();
+  if (wave == 0) add(slot[0]);
+  if (wave == 2) add(slot[1]);
+  __syncthreads();
+  if (wave == 2) put(slot[0]);
+  __syncthreads();
+  if (wave != 0) return;
+  add(slot[0]);
+  // lane l of block (mb, nb): output column n = n0 + 16 nb + 4 (l >> 4) + g (g = the accumulator's register), row m = m0 + 16 mb + (l & 15)
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m = m0 + 16 * mb + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int n = n0 + 16 * nb + 4 * (lane >> 4);
+      if (n >= N) continue;   // N % 4 == 0: the four columns are inside or outside together
+      f32x4 v = acc[mb][nb];
+      if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+      if (epi == GEPI_ACT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = tr_act(v[g], act);
+      }
+      f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)m * ldo + n);
+      *o = accumulate ? *o + v : v;
+    }
+  }
+}
+
 static void gemm_nt(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldo, int M, int N,
                     int K, bool accumulate = false, int epi = GEPI_NONE, int act = 0, const float* aux = nullptr, int ldaux = 0) {
-  const dim3 grid((N + 15) / 16, (M + 15) / 16);
   const int acc = accumulate ? 1 : 0;
+  // (only where the 64 x 64 tiles still fill the chip twice over: at the tape's 320 - 1,920 rows the small tiles' 10 x as many
+  //  workgroups win - 2.07 against 2.46 ms for the rk4 training step)
+  if ((long)((M + 63) / 64) * ((N + 63) / 64) >= 512 && N % 4 == 0 && ldo % 4 == 0 && epi != GEPI_DACT && getenv("ODEVIO_NT_NARROW") == nullptr &&
+      (((uintptr_t)out | (uintptr_t)bias) & 15) == 0) {
+    hipLaunchKernelGGL(gemm_nt64_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K, acc, epi, act);
+    return;
+  }
+  const dim3 grid((N + 15) / 16, (M + 15) / 16);
   if (K <= 512)
     hipLaunchKernelGGL((gemm_nt_kernel<8, 4>), grid, dim3(256), 0, st, A, lda, W, ldw, bias, out, ldo, M, N, K, acc, epi, act, aux, ldaux);
   else if (K <= 1024 || grid.x * grid.y >= 512)   // (a grid that fills the chip anyway keeps the small workgroups)

@@ -111,8 +111,10 @@ def test_adaptive_solver_backward_replays_the_accepted_steps(cfg):
     assert not bad, f"gradients off by more than {GTOL}: {bad}"
 
 
-@pytest.mark.parametrize("cfg", [dict(ode_solver="rk4", ode_substeps=2), dict(ode_solver="dopri5", ode_rnn_type="gru")])
-def test_taped_backward_equals_the_plain_one_and_the_step_by_step_tape(cfg, monkeypatch):
+@pytest.mark.parametrize("cfg,B", [(dict(ode_solver="rk4", ode_substeps=2), 5), (dict(ode_solver="dopri5", ode_rnn_type="gru"), 5),
+                                   (dict(ode_solver="rk4"), 40),                       # two chunks of rows (32 + 8 sequences) per persistent launch
+                                   (dict(ode_solver="heun", rnn_num_layers=3), 19)])   # three RNN layers: chunks of 16 sequences
+def test_taped_backward_equals_the_plain_one_and_the_step_by_step_tape(cfg, B, monkeypatch):
     """Three routes to the same gradients: (a) the autograd function (odevio_ode_rnn_fwd_taped keeps the forward's log, _bwd_taped reads
     it: the persistent kernel runs once per step), (b) the plain pair (the backward runs the forward again to write the same log) -
     the same arithmetic on the same log, so bit-equal - and (c) ODEVIO_TAPE_IN_ORDER=1: no logged states, the tape walks the steps in
@@ -121,7 +123,7 @@ def test_taped_backward_equals_the_plain_one_and_the_step_by_step_tape(cfg, monk
     from odevio_amd import _lib
     opt = default_opt(img_h=64, img_w=128, **cfg)
     model, _ = make_model(opt, seed=74)
-    B, P, L, F = 5, 4, opt.rnn_num_layers, 768
+    P, L, F = 4, opt.rnn_num_layers, 768
     g = torch.Generator().manual_seed(8)
     fused = torch.randn(B, P, F, generator=g).cuda()
     ts = synth.timestamps(B, P + 1, drop=0.4, seed=5, absolute=True).cuda()

@@ -25,7 +25,7 @@ img = torch.rand(B, S, 3, opt.img_h, opt.img_w, device="cuda") - 0.5
 for _ in range(int(os.environ.get("ODEVIO_STAMP_WARM", "300"))):   # back-to-back launches first: the clock the chip holds under this load
     m.image_encoder(img)
 torch.cuda.synchronize()
-out = (ctypes.c_uint64 * 8)()
+out = (ctypes.c_uint64 * 12)()
 _lib.check(m._lib.odevio_debug_stamps(m._plan, ctypes.cast(out, ctypes.c_void_p), m._stream()))
 t0, t1, t2, t3, nt = out[0], out[1], out[2], out[3], out[4]
 name = weights.IMAGE_CONVS[i][0]

@@ -14,11 +14,14 @@ for solver, B, safe in (("rk4", 16, "0"), ("rk4", 16, "1"), ("dopri5", 16, "0"),
     for _ in range(3):
         m.pose_net(fv, fi, ts)
     torch.cuda.synchronize()
-    out = (ctypes.c_uint64 * 8)()
+    out = (ctypes.c_uint64 * 12)()
     _lib.check(m._lib.odevio_debug_stamps(m._plan, ctypes.cast(out, ctypes.c_void_p), None))
     tot, tg, tl, tr, ng = [int(x) for x in out[:5]]
     local = [(int(out[5]) >> (8 * g)) & 1 for g in range(8)]
     print(f"   post-layer barrier {100*int(out[6])/tot:.1f}%  owner epilogue {100*int(out[7])/tot:.1f}%")
+    pro, fev, nrm, rnp = [int(x) for x in out[8:12]]
+    print(f"   by section: launch -> first interval {100*pro/tot:.1f}%  vector-field evaluations {100*fev/tot:.1f}%  error norm + controller {100*nrm/tot:.1f}%  "
+          f"RNN phases {100*rnp/tot:.1f}%  Runge-Kutta arithmetic and the rest {100*(tot-pro-fev-nrm-rnp)/tot:.1f}%")
     # production library timing of the same call (events on the current stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
