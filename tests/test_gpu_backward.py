@@ -175,6 +175,47 @@ def test_taped_backward_equals_the_plain_one_and_the_step_by_step_tape(cfg, B, m
     assert any(not torch.equal(a[k], c[k]) for k in a)     # (the two tapes really are different routes)
 
 
+@pytest.mark.parametrize("widths,rows", [((200, 200), (32, 20)), ((512, 256), (7, 100))])
+def test_soft_fusion_backward_over_many_rows(widths, rows, monkeypatch):
+    """FusionModule 'soft' backward with hundreds of rows: the weight gradient is the wide-tile TN product (64 x 64 tiles, rows split over
+    workgroup layers, bias sums from the same launch) incl. its ragged edges at the reference recipe's 200 + 200 = 400 columns - against
+    autograd through the oracle in float64, and against the narrow-tile form of the same product."""
+    from odevio_amd import _lib
+    v, i = widths
+    B, P = rows
+    opt = default_opt(img_h=64, img_w=128, model_type="rnn", fuse_method="soft", v_f_len=v, i_f_len=i)
+    model, sd = make_model(opt, seed=75)
+    g = torch.Generator().manual_seed(9)
+    fv, fi = torch.randn(B, P, v, generator=g), torch.randn(B, P, i, generator=g)
+    gout = torch.randn(B, P, v + i, generator=g)
+    names = train.fuse_param_names(opt)
+    leaves = {n: sd[n].clone().double().requires_grad_(True) for n in names}
+    fv64, fi64 = fv.double().requires_grad_(True), fi.double().requires_grad_(True)
+    oc.fuse({**sd, **leaves}, fv64, fi64, "soft", dtype=torch.float64).backward(gout.double())
+    params = dict(model.named_parameters())
+
+    def run():
+        for n in names:
+            params[n].grad = None
+        fvd, fid = fv.cuda().requires_grad_(True), fi.cuda().requires_grad_(True)
+        fused = train._FuseFunction.apply(model, names, fvd, fid, *[params[n] for n in names])
+        fused.backward(gout.cuda())
+        model.check()
+        return {"fv": fvd.grad, "fi": fid.grad, **{n: params[n].grad.clone() for n in names}}
+
+    model._ensure_plan()
+    got = run()
+    ref = {"fv": fv64.grad, "fi": fi64.grad, **{n: leaves[n].grad for n in names}}
+    bad = {k: f"{oc.rel_err(got[k], ref[k]):.2e}" for k in ref if not oc.rel_err(got[k], ref[k]) < GTOL}
+    assert not bad, bad
+    monkeypatch.setenv("ODEVIO_TN_NARROW", "1")
+    narrow = run()
+    monkeypatch.delenv("ODEVIO_TN_NARROW")
+    for k in got:
+        assert oc.rel_err(got[k], narrow[k]) < 2e-5, (k, oc.rel_err(got[k], narrow[k]))
+    assert any(not torch.equal(got[n], narrow[n]) for n in names)     # (really two kernels)
+
+
 def test_euler_backward_replays_every_dt0_step():
     """euler under torchode's controller (PoseODERNN.py:125-137) has no error estimate: every dt0 = 1e-4 step is accepted until the
     interval's end (the last one clipped) - a thousand steps per 0.1 s.  The backward replays them like any logged step sequence; short
