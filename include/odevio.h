@@ -289,6 +289,14 @@ int odevio_adam_step(float* param, const float* grad, float* exp_avg, float* exp
  * p -= lr * buf.  norm_coef: the device pair written by odevio_grad_clip, or NULL. */
 int odevio_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t numel, float lr, float momentum, float weight_decay,
                     int32_t step, const float* norm_coef, void* stream);
+/* The same updates for a whole list of tensors in ONE call and one launch (what a training step does: the reference's optimizer.step()
+ * over Pose_net's ~20 parameter tensors, utils/utils.py:115-130): kind 0 = torch.optim.Adam (state1 = exp_avg, state2 = exp_avg_sq, beta1 /
+ * beta2), kind 1 = torch.optim.SGD (state1 = momentum buffers or NULL, beta1 = momentum; beta2 / eps unused).  params / grads / state*: n
+ * device tensors each (odevio_tensor.data, .numel; sizes must agree), lrs: n HOST floats (the reference's two learning-rate groups),
+ * step >= 1 (1-based, shared), norm_coef: the device pair written by odevio_grad_clip, or NULL. */
+int odevio_optimizer_step(int32_t kind, const odevio_tensor* params, const odevio_tensor* grads, const odevio_tensor* state1,
+                          const odevio_tensor* state2, const float* lrs, int32_t n, float beta1, float beta2, float eps, float weight_decay,
+                          int32_t step, const float* norm_coef, void* stream);
 
 /* After an optimizer step: re-reads the parameters of Pose_net (fusion, regressor, ODEFunc, RNN; every key of the
  * reference's Pose_net state_dict, device pointers) into the plan's kernel layouts, in place.  The encoders are not

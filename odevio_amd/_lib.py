@@ -29,7 +29,7 @@ SYMBOLS = [
     "odevio_rng_state", "odevio_debug_gumbel", "odevio_fuse_hard_bwd", "odevio_set_rng_state",
     "odevio_image_encoder_fwd_train", "odevio_imu_encoder_fwd_train", "odevio_imu_encoder_bwd_train", "odevio_debug_dropout",
     "odevio_sgd_step", "odevio_image_encoder_bwd", "odevio_cde_bwd",
-    "odevio_ode_rnn_tape_floats", "odevio_ode_rnn_fwd_taped", "odevio_ode_rnn_bwd_taped",
+    "odevio_ode_rnn_tape_floats", "odevio_ode_rnn_fwd_taped", "odevio_ode_rnn_bwd_taped", "odevio_optimizer_step",
 ]
 
 
@@ -121,6 +121,8 @@ def load():
     lib.odevio_grad_clip.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, f32, fp, vp]
     lib.odevio_adam_step.argtypes = [fp, fp, fp, fp, ctypes.c_int64, f32, f32, f32, f32, f32, i32, fp, vp]
     lib.odevio_sgd_step.argtypes = [fp, fp, fp, ctypes.c_int64, f32, f32, f32, i32, fp, vp]
+    tp = ctypes.POINTER(OdevioTensor)
+    lib.odevio_optimizer_step.argtypes = [i32, tp, tp, tp, tp, ctypes.POINTER(f32), i32, f32, f32, f32, f32, i32, fp, vp]
     lib.odevio_plan_update.argtypes = [vp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_imu_encoder_bwd.argtypes = [vp, fp, i32, i32, fp, ctypes.POINTER(OdevioTensor), i32, vp]
     lib.odevio_set_seed.argtypes = [vp, ctypes.c_uint64]

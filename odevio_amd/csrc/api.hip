@@ -2551,6 +2551,33 @@ extern "C" int odevio_sgd_step(float* param, const float* grad, float* momentum_
   return 0;
 }
 
+extern "C" int odevio_optimizer_step(int32_t kind, const odevio_tensor* params, const odevio_tensor* grads, const odevio_tensor* state1,
+                                     const odevio_tensor* state2, const float* lrs, int32_t n, float beta1, float beta2, float eps,
+                                     float weight_decay, int32_t step, const float* norm_coef, void* stream) {
+  ARGCHK((kind == 0 || kind == 1) && params && grads && lrs && n > 0 && step >= 1 && weight_decay >= 0.f && beta1 >= 0.f && beta1 < 1.f,
+         "odevio_optimizer_step: bad argument");
+  if (kind == 0) ARGCHK(state1 && state2 && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, "odevio_optimizer_step: Adam needs both state tensors, betas in [0, 1), eps > 0");
+  if (kind == 1) ARGCHK(state1 || beta1 == 0.f, "odevio_optimizer_step: SGD with momentum needs its buffers");
+  for (int i = 0; i < n; ++i) {
+    const bool ok = params[i].data && grads[i].data && params[i].numel > 0 && grads[i].numel == params[i].numel && lrs[i] >= 0.f &&
+                    (!state1 || (state1[i].data && state1[i].numel == params[i].numel)) && (kind != 0 || (state2[i].data && state2[i].numel == params[i].numel));
+    if (!ok) return fail(ODEVIO_ERR_BAD_ARG, "odevio_optimizer_step: tensor %d ('%s'): missing pointer or sizes that differ", i, params[i].name ? params[i].name : "");
+  }
+  for (int t0 = 0; t0 < n; t0 += OPT_TABLE_MAX) {
+    OptTable t;
+    t.n = std::min(OPT_TABLE_MAX, n - t0);
+    for (int i = 0; i < t.n; ++i) {
+      const int k = t0 + i;
+      t.e[i].p = (float*)params[k].data; t.e[i].g = (const float*)grads[k].data;
+      t.e[i].s1 = state1 ? (float*)state1[k].data : nullptr; t.e[i].s2 = (kind == 0) ? (float*)state2[k].data : nullptr;
+      t.e[i].n = (size_t)params[k].numel; t.e[i].lr = lrs[k];
+    }
+    if (train_optimizer_multi(t, kind, beta1, beta2, eps, weight_decay, step, norm_coef, (hipStream_t)stream))
+      return fail(ODEVIO_ERR_HIP, "odevio_optimizer_step: launch failed");
+  }
+  return 0;
+}
+
 extern "C" int odevio_pose_loss(const float* poses, const float* gts, int32_t n_rows, float* loss3, float* grad_poses, void* stream) {
   ARGCHK(poses && gts && loss3 && n_rows > 0, "odevio_pose_loss: bad argument");
   if (train_pose_loss(poses, gts, n_rows, loss3, grad_poses, (hipStream_t)stream)) return fail(ODEVIO_ERR_HIP, "odevio_pose_loss: launch failed");

@@ -60,6 +60,20 @@ int train_grad_clip(const float* const* grads, const size_t* numel, int n, float
 // one torch.optim.Adam update of one tensor; clip2 = the device pair written by train_grad_clip (or null)
 int train_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step,
                     const float* clip2, hipStream_t st);
+// many tensors, one launch: kind 0 = Adam (s1 = exp_avg, s2 = exp_avg_sq, b1 / b2 the betas), 1 = SGD (s1 = momentum buffer, b1 = momentum)
+#define OPT_TABLE_MAX 64
+struct OptEntry {
+  float* p;
+  const float* g;
+  float *s1, *s2;
+  size_t n;
+  float lr;
+};
+struct OptTable {
+  OptEntry e[OPT_TABLE_MAX];
+  int n;
+};
+int train_optimizer_multi(const OptTable& t, int kind, float b1, float b2, float eps, float wd, int step, const float* clip2, hipStream_t st);
 // one torch.optim.SGD update (momentum buffer `buf`; step 1 initialises it with the gradient like torch does)
 int train_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int step, const float* clip2,
                    hipStream_t st);

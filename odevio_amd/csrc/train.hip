@@ -1016,9 +1016,27 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict
     out[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
   }
 }
+// the same partial sums for up to OPT_TABLE_MAX tensors in one launch (blockIdx.y = tensor; entries' p = the gradient)
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(OptTable t, double* __restrict__ partial) {
+  __shared__ double red[256];
+  const OptEntry e = t.e[blockIdx.y];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (size_t)NORM_BLOCKS * 256) s += (double)e.g[i] * (double)e.g[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * NORM_BLOCKS + blockIdx.x] = red[0];
+}
 int train_grad_clip(const float* const* grads, const size_t* numel, int n, float max_norm, double* partial_ws, float* out2, hipStream_t st) {
-  for (int t = 0; t < n; ++t)
-    hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, grads[t], numel[t], partial_ws + (size_t)t * NORM_BLOCKS);
+  for (int t0 = 0; t0 < n; t0 += OPT_TABLE_MAX) {
+    OptTable t;
+    t.n = std::min(OPT_TABLE_MAX, n - t0);
+    for (int i = 0; i < t.n; ++i) { t.e[i].g = grads[t0 + i]; t.e[i].n = numel[t0 + i]; t.e[i].p = nullptr; t.e[i].s1 = t.e[i].s2 = nullptr; t.e[i].lr = 0.f; }
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(NORM_BLOCKS, t.n), dim3(256), 0, st, t, partial_ws + (size_t)t0 * NORM_BLOCKS);
+  }
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, partial_ws, n * NORM_BLOCKS, max_norm, out2);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
@@ -1049,6 +1067,50 @@ int train_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
   const float bc1 = 1.f - powf(b1, (float)step);
   const float sqrt_bc2 = sqrtf(1.f - powf(b2, (float)step));
   hipLaunchKernelGGL(adam_kernel, EW_GRID(n), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrt_bc2, clip2);
+  return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
+}
+
+// The same two updates over MANY tensors in one launch (blockIdx.y = tensor): a training step's twenty parameter tensors were twenty
+// host calls and twenty launches of a few microseconds of work each.  Same arithmetic per element as adam_kernel / sgd_kernel.
+__global__ void optimizer_multi_kernel(OptTable t, int kind, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2, int first,
+                                       const float* __restrict__ clip2) {
+  const OptEntry e = t.e[blockIdx.y];
+  const float clip = clip2 ? clip2[1] : 1.0f;
+  if (kind == 0) {
+    const float step_size = e.lr / bc1;
+    EW_LOOP(i, e.n) {
+      const float pi = e.p[i];
+      float gi = e.g[i] * clip;
+      if (wd != 0.f) gi = fmaf(wd, pi, gi);
+      const float m0 = e.s1[i];
+      const float mi = fmaf(gi - m0, 1.f - b1, m0);
+      const float vi = fmaf(b2, e.s2[i], (1.f - b2) * gi * gi);
+      e.s1[i] = mi;
+      e.s2[i] = vi;
+      const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+      e.p[i] = pi - step_size * (mi / denom);
+    }
+  } else {
+    EW_LOOP(i, e.n) {
+      const float pi = e.p[i];
+      float gi = e.g[i] * clip;
+      if (wd != 0.f) gi = fmaf(wd, pi, gi);
+      float bi = gi;
+      if (b1 != 0.f) {   // b1 = momentum
+        bi = first ? gi : fmaf(b1, e.s1[i], gi);
+        e.s1[i] = bi;
+      }
+      e.p[i] = pi - e.lr * bi;
+    }
+  }
+}
+int train_optimizer_multi(const OptTable& t, int kind, float b1, float b2, float eps, float wd, int step, const float* clip2, hipStream_t st) {
+  const float bc1 = kind == 0 ? 1.f - powf(b1, (float)step) : 1.f;
+  const float sqrt_bc2 = kind == 0 ? sqrtf(1.f - powf(b2, (float)step)) : 1.f;
+  size_t most = 0;
+  for (int i = 0; i < t.n; ++i) most = std::max(most, t.e[i].n);
+  const unsigned bx = (unsigned)std::min<size_t>((most + 255) / 256, 256);
+  hipLaunchKernelGGL(optimizer_multi_kernel, dim3(bx, t.n), dim3(256), 0, st, t, kind, b1, b2, eps, wd, bc1, sqrt_bc2, step <= 1 ? 1 : 0, clip2);
   return hipGetLastError() == hipSuccess ? 0 : ODEVIO_ERR_HIP;
 }
 

@@ -414,6 +414,13 @@ class PoseNetTrainer:
             model.set_seed((seed + 0x9E3779B97F4A7C15 * (tdist.get_rank(process_group) + 1)) & 0xFFFFFFFFFFFFFFFF)
         self.norm_coef = torch.zeros(2, device=self.params[0].device, dtype=torch.float32)   # {total grad norm, clip factor}
         self.steps = 0
+        # what never changes between steps (parameters and optimizer state are updated IN PLACE): the tensor tables of the one-call
+        # optimizer step and of the plan refresh, and the list of every parameter of the model (the clipping norm looks at all of them)
+        self._param_table = _tensor_array(self.names, [p.detach() for p in self.params])
+        self._state1_table = _tensor_array(self.names, self.exp_avg)
+        self._state2_table = _tensor_array(self.names, self.exp_avg_sq) if self.exp_avg_sq else None
+        self._param_ptrs = [p.data_ptr() for p in self.params]
+        self._all_named = [(n, p) for n, p in model.named_parameters() if n not in self._name_set]
 
     def set_epoch(self, ep):
         """The reference's per-epoch schedule (train_model.py:25-35, 211-215): lr_warmup for the first epochs_warmup epochs,
@@ -443,7 +450,7 @@ class PoseNetTrainer:
             grads.append(p.grad.contiguous().float())
         stream = model._stream()
         model._ensure_plan()
-        extra_pairs = [(n, p) for n, p in model.named_parameters() if p.grad is not None and n not in self._name_set]
+        extra_pairs = [(n, p) for n, p in self._all_named if p.grad is not None]
         if self._world() > 1:
             from . import dist as _dist
             for _, p in extra_pairs:
@@ -460,17 +467,20 @@ class PoseNetTrainer:
         _lib.check(lib.odevio_grad_clip(model._plan, _tensor_array(self.names + extra_names, grads + extra), len(grads) + len(extra),
                                         self.gradient_clip, self.norm_coef.data_ptr(), stream))
         self.steps += 1
-        for i, (n, p, g) in enumerate(zip(self.names, self.params, grads)):
-            lr = self.lr_regressor if n.startswith("Pose_net.regressor.") else self.lr
-            if self.optimizer == "Adam":
-                _lib.check(lib.odevio_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr(), p.numel(), lr,
-                                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps, self.norm_coef.data_ptr(),
-                                                stream))
-            else:   # torch.optim.SGD(param_groups, lr=1e-4, momentum=0.9): the groups' lr_warmup overrides 1e-4, no weight decay
-                _lib.check(lib.odevio_sgd_step(p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), p.numel(), lr, 0.9, 0.0, self.steps,
-                                               self.norm_coef.data_ptr(), stream))
+        # optimizer.step() over every Pose_net tensor in one call (two learning-rate groups, utils/utils.py:116-119)
+        lrs = (ctypes.c_float * len(grads))(*[self.lr_regressor if n.startswith("Pose_net.regressor.") else self.lr for n in self.names])
+        if [p.data_ptr() for p in self.params] != self._param_ptrs:   # (somebody replaced a parameter's storage: rebuild the table)
+            self._param_table = _tensor_array(self.names, [p.detach() for p in self.params])
+            self._param_ptrs = [p.data_ptr() for p in self.params]
+        pa, s1 = self._param_table, self._state1_table
+        ga = _tensor_array(self.names, grads)
+        if self.optimizer == "Adam":
+            _lib.check(lib.odevio_optimizer_step(0, pa, ga, s1, self._state2_table, lrs, len(grads), self.betas[0], self.betas[1],
+                                                 self.eps, self.weight_decay, self.steps, self.norm_coef.data_ptr(), stream))
+        else:   # torch.optim.SGD(param_groups, lr=1e-4, momentum=0.9): the groups' lr_warmup overrides 1e-4, no weight decay
+            _lib.check(lib.odevio_optimizer_step(1, pa, ga, s1, None, lrs, len(grads), 0.9, 0.0, 0.0, 0.0, self.steps, self.norm_coef.data_ptr(), stream))
         # the kernels read their own layouts of these parameters (column shards, transposes): refresh them in place
-        rc = lib.odevio_plan_update(model._plan, _tensor_array(self.names, [p.detach() for p in self.params]), len(self.params), stream)
+        rc = lib.odevio_plan_update(model._plan, pa, len(self.params), stream)
         if rc == _lib.ERR_UNSUPPORTED:      # widths the integrator pads (F = 400, H = 200): no in-place re-layout - rebuild the plan at the next forward
             model._plan_sig = None
             return True

@@ -60,6 +60,7 @@ int main(void) {
   EXPECT(odevio_cde_bwd(NULL, x, 1, 2, NULL, 1, NULL, x, NULL, x, NULL, NULL, 0, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   EXPECT(odevio_debug_dropout(0, 0, 1.5f, 4, x, NULL) == ODEVIO_ERR_BAD_ARG);     /* p must be < 1 */
   EXPECT(odevio_sgd_step(x, x, NULL, 4, 1e-4f, 0.9f, 0.0f, 1, NULL, NULL) == ODEVIO_ERR_BAD_ARG);   /* momentum needs its buffer */
+  EXPECT(odevio_optimizer_step(2, NULL, NULL, NULL, NULL, NULL, 1, 0.9f, 0.999f, 1e-8f, 0.0f, 1, NULL, NULL) == ODEVIO_ERR_BAD_ARG);
   {
     int64_t n = -1;
     EXPECT(odevio_ode_rnn_tape_floats(NULL, 1, 1, &n) == ODEVIO_ERR_BAD_ARG);
