@@ -30,6 +30,7 @@ struct WgradArgs {
   int cin_out;         // real input channels (0 = Cin); conv1 presents its 6 channels in 8 slots
   int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int M, splits, chunks_per_split;
+  int fold_kw;         // (set by enc_wgrad) conv1's form: the 64 tile columns are (kw, channel slot) of one filter row
 };
 size_t enc_wgrad_partial_floats(int Cout, int Cin, int taps, int splits);
 int enc_wgrad_pick_splits(int M, int Cout, int Cin, int taps);

@@ -3,6 +3,7 @@
 // layout of the forward activations cannot carry without per-tensor exponents; the fp32-input MFMA (v_mfma_f32_16x16x4_f32, an
 // exact fmaf chain) does the contractions.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "enc_bwd.h"
@@ -128,8 +129,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int taps = a.KH * a.KW;
-  const int tap = blockIdx.x % taps, split = blockIdx.x / taps;
-  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  // conv1 (6 channels in 8 slots): a 64-wide tile of input channels would multiply 56 columns of zeros per tap - and did, as many
+  // MFMAs as all the other layers together.  Folded form: the tile's 64 columns are (kw, channel slot) of ONE filter row, a
+  // workgroup per kh; column j of the loader / of the result = (kw = j / 8, slot = j % 8).
+  const bool fold = a.fold_kw != 0;
+  const int gtaps = fold ? a.KH : taps;
+  const int tap = blockIdx.x % gtaps, split = blockIdx.x / gtaps;
+  const int kh = fold ? tap : tap / a.KW;
   const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
   const int wr = wave >> 1, wc = wave & 1;
   f32x4 acc[2][2];
@@ -144,7 +150,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const int G = a.Cin >> 5;
   const int chunk_begin = split * a.chunks_per_split;
   const int chunk_end = min((split + 1) * a.chunks_per_split, (a.M + WG_PX - 1) / WG_PX);
-  const bool co_ok = co0 + lcol < a.Cout, ci_ok = ci0 + lcol < a.Cin;
+  const int kw = fold ? (lcol >> 3) : tap - kh * a.KW;          // (folded: this loader thread's own filter column)
+  const bool co_ok = co0 + lcol < a.Cout, ci_ok = fold ? kw < a.KW : ci0 + lcol < a.Cin;
   // (image, row, column) of this thread's four loader rows, advanced by carries from chunk to chunk (two divisions per row ONCE, not per chunk:
   // the address arithmetic of the first version cost as much issue time as the MFMAs)
   int pn[4], pho[4], pwo[4];
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int hi = pho[j] * a.stride + kh - a.pad, wi = pwo[j] * a.stride + kw - a.pad;
         if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi && ci_ok) {
           const size_t pi = ((size_t)pn[j] * a.Hi + hi) * a.Wi + wi;
-          const int ci = ci0 + lcol;
+          const int ci = fold ? (lcol & 7) : ci0 + lcol;
           if (a.x_f32) {
             xv[j] = *reinterpret_cast<const f32x4*>(xf + pi * a.ldx + ci);
           } else {
@@ -211,15 +218,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
   }
   // C/D map of the 16x16x4 MFMA: lane (r, q), register e = [row 4 q + e][column r] = [co][ci]
-  float* slab = a.partial + ((size_t)split * taps + tap) * a.Cout * a.Cin;
+  const size_t per = (size_t)a.Cout * a.Cin;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int co = co0 + wr * 32 + 16 * i + 4 * q + e, ci = ci0 + wc * 32 + 16 * j + r;
-        if (co < a.Cout && ci < a.Cin) slab[(size_t)co * a.Cin + ci] = acc[i][j][e];
+        const int co = co0 + wr * 32 + 16 * i + 4 * q + e, col = wc * 32 + 16 * j + r;
+        const int ci = fold ? (col & 7) : ci0 + col;
+        const int t = fold ? kh * a.KW + (col >> 3) : tap;
+        if (co < a.Cout && ci < a.Cin && (!fold || (col >> 3) < a.KW)) a.partial[((size_t)split * taps + t) * per + (size_t)co * a.Cin + ci] = acc[i][j][e];
       }
 }
 // slabs in slab order -> dW [Cout][Cin][KH][KW]
@@ -358,8 +367,12 @@ hipError_t enc_bn_bwd_apply(const float* g_a, const void* z, size_t M, int C, co
 
 size_t enc_wgrad_partial_floats(int Cout, int Cin, int taps, int splits) { return (size_t)splits * taps * Cout * Cin; }
 
+// conv1's shape: the filter row folded into the tile's columns (wgrad_kernel)
+static bool wgrad_folds(int Cin, int KW, int x_f32) { return x_f32 && Cin == 8 && KW * 8 <= 64; }
+
 int enc_wgrad_pick_splits(int M, int Cout, int Cin, int taps) {
-  const long tiles = (long)taps * ((Cout + 63) / 64) * ((Cin + 63) / 64);
+  long tiles = (long)taps * ((Cout + 63) / 64) * ((Cin + 63) / 64);
+  if (Cin == 8 && taps == 49) tiles = 7L * ((Cout + 63) / 64);     // (the folded form launches a workgroup per filter ROW)
   const int chunks = (M + WG_PX - 1) / WG_PX;
   long s = (2048 + tiles - 1) / tiles;            // ~8 workgroups per CU in flight over the launch
   s = std::max(1L, std::min<long>(s, chunks));
@@ -377,8 +390,12 @@ hipError_t enc_wgrad(const WgradArgs& a_in, hipStream_t st) {
   a.chunks_per_split = (chunks + a.splits - 1) / a.splits;
   a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
   const int taps = a.KH * a.KW;
+  a.fold_kw = wgrad_folds(a.Cin, a.KW, a.x_f32) && getenv("ODEVIO_WGRAD_NO_FOLD") == nullptr ? 1 : 0;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(wgrad_kernel, dim3(taps * a.splits, (a.Cout + 63) / 64, (a.Cin + 63) / 64), dim3(256), 0, st, a);
+  if (a.fold_kw)
+    hipLaunchKernelGGL(wgrad_kernel, dim3(a.KH * a.splits, (a.Cout + 63) / 64, 1), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(wgrad_kernel, dim3(taps * a.splits, (a.Cout + 63) / 64, (a.Cin + 63) / 64), dim3(256), 0, st, a);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_blocks((size_t)a.Cout * a.Cin * taps)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
