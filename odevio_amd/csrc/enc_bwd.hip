@@ -122,7 +122,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // x[pixel q][ci r] - no transpose anywhere.  64-pixel chunks are staged in LDS (row stride 80 floats: the two 32-lane halves of a
 // ds_read_b32 then touch 32 different banks).
 // ---------------------------------------------------------------------------------------------------------------------
-#define WG_PX 64
+// pixels per chunk: measured 16 / 32 / 64 / 128 -> Image_net backward 64.2 / 64.2 / 69.6 / 85.4 ms at the bench batch: the kernel lives on
+// the number of workgroups a CU holds (its loads are latency, 40 KB of LDS per workgroup at 64 pixels allowed four)
+#ifndef WG_PX
+#define WG_PX 32
+#endif
+#define WG_ROWS (WG_PX / 16)   // loader rows per thread and chunk
 #define WG_LD 80
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   __shared__ float Dt[WG_PX * WG_LD], Xt[WG_PX * WG_LD];
@@ -154,19 +159,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const bool co_ok = co0 + lcol < a.Cout, ci_ok = fold ? kw < a.KW : ci0 + lcol < a.Cin;
   // (image, row, column) of this thread's four loader rows, advanced by carries from chunk to chunk (two divisions per row ONCE, not per chunk:
   // the address arithmetic of the first version cost as much issue time as the MFMAs)
-  int pn[4], pho[4], pwo[4];
+  int pn[WG_ROWS], pho[WG_ROWS], pwo[WG_ROWS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < WG_ROWS; ++j) {
     const int m = chunk_begin * WG_PX + lrow + 16 * j;
     pn[j] = m / HoWo;
     const int rem = m - pn[j] * HoWo;
     pho[j] = rem / a.Wo;
     pwo[j] = rem - pho[j] * a.Wo;
   }
-  f32x4 dv[4], xv[4];
+  f32x4 dv[WG_ROWS], xv[WG_ROWS];
   auto fetch = [&](int ch) __attribute__((always_inline)) {   // chunk ch -> registers (the loads stay in flight under the previous chunk's MFMAs)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WG_ROWS; ++j) {
       const int m = ch * WG_PX + lrow + 16 * j;
       dv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   for (int ch = chunk_begin; ch < chunk_end; ++ch) {
     __syncthreads();                                    // every wave is done reading the previous chunk
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WG_ROWS; ++j) {
       *reinterpret_cast<f32x4*>(&Dt[(lrow + 16 * j) * WG_LD + lcol]) = dv[j];
       *reinterpret_cast<f32x4*>(&Xt[(lrow + 16 * j) * WG_LD + lcol]) = xv[j];
     }
