@@ -16,6 +16,7 @@ bash tools/gpu_run.sh ${TAG}x \
   "time_backward_dopri5_gru|200|python tools/time_backward.py dopri5 gru" \
   "time_cde_backward|400|python tools/time_cde_backward.py 1024" \
   "bench_line|300|python bench.py" \
+  "forward_sizes|300|python tools/time_forward_sizes.py" \
   "bench_dopri5|200|python bench.py --ode-solver dopri5 --drop 0.5 --no-cpu-baseline --no-f32-reference" \
   "bench_fp16|200|python bench.py --dtype fp16 --no-cpu-baseline" || exit $?
 mkdir -p $OUT/prof_${TAG}train
