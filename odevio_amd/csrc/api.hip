@@ -111,6 +111,8 @@ struct odevio_plan {
   float* conv_wT[9] = {};                  // [Cin][kh][kw][Cout], taps reversed (blocks 1..8): fp32-input MFMA form (ODEVIO_ENC_BWD_IGEMM)
   void* conv_wTs[9] = {};                  // the same filters as two fp16 pieces for conv_f16x2_kernel: [Cin][K-tile][2][32]
   size_t conv_wTs_bytes[9] = {};
+  void* conv_wTp[9][4] = {};               // 5 x 5 stride-2 blocks: the four PARITY sub-filters (3 x 3, one per (row, column) parity of the input pixel)
+  size_t conv_wTp_bytes[9] = {};
   float conv_wT_inv_prescale[9] = {};
   float* enc_dscale = nullptr;             // [1024] epilogue scale of the current input-gradient convolution + one word for max|D|
   DevBuf enc_z[9], enc_a[9];
@@ -693,6 +695,34 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
         TRY(dev_alloc(p, &p->conv_wTs[i], wts.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpyAsync(p->conv_wTs[i], wts.data(), wts.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (cs.k == 5 && cs.stride == 2) {
+          // The input gradient of a stride-2 block without multiplying the zeros of a dilated gradient: input pixel (2i + py, 2j + px)
+          // only meets the taps kh = py (mod 2), kw = px (mod 2) (pad 2), so each parity class is a stride-1 3 x 3 correlation of
+          // the UNdilated gradient:  g_x[2i+py][2j+px] = sum_t D[i + ty - 1][j + tx - 1] W[2 (2 - ty) + py][2 (2 - tx) + px]
+          // (taps that fall outside 0..4 are zero: 9 + 6 + 6 + 4 of 36 slots carry weights - against 25 of 100 slots of the dilated form).
+          std::vector<float> wc((size_t)4 * cs.cin * cs.cout * 9, 0.f);
+          for (int cl = 0; cl < 4; ++cl)
+            for (int c = 0; c < cs.cin; ++c)
+              for (int n = 0; n < cs.cout; ++n)
+                for (int ty = 0; ty < 3; ++ty)
+                  for (int tx = 0; tx < 3; ++tx) {
+                    const int kh = 2 * (2 - ty) + (cl >> 1), kw = 2 * (2 - tx) + (cl & 1);
+                    if (kh > 4 || kw > 4) continue;
+                    wc[(((size_t)cl * cs.cin + c) * cs.cout + n) * 9 + ty * 3 + tx] = w[((size_t)n * cs.cin + c) * 25 + kh * 5 + kw];
+                  }
+          std::vector<uint16_t> wps;
+          const float ps4 = split_conv_weights(wc, 4 * cs.cin, cs.cout, 9, wps);    // one prescale for the four (= the whole filter's: every tap is in one class)
+          if (1.0f / ps4 != p->conv_wT_inv_prescale[i]) return fail(ODEVIO_ERR_BAD_ARG, "parity sub-filters: prescale differs from the whole filter's");
+          const size_t per = wps.size() / 4;
+          p->conv_wTp_bytes[i] = per * sizeof(uint16_t);
+          for (int cl = 0; cl < 4; ++cl) {
+            std::vector<uint16_t> one(wps.begin() + cl * per, wps.begin() + (cl + 1) * per);
+            one.resize(one.size() + ODEVIO_ZERO_PAGE_BYTES / sizeof(uint16_t), 0);
+            TRY(dev_alloc(p, &p->conv_wTp[i][cl], one.size() * sizeof(uint16_t)));
+            HIPCHK(hipMemcpyAsync(p->conv_wTp[i][cl], one.data(), one.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+          }
+        }
       }
     }
     TRY(upload(p, &p->conv_scale[i], sc, st));
@@ -1350,6 +1380,41 @@ static int image_encoder_bwd(odevio_plan* p, const float* img, int B, int S, con
       Wd = Wi + 2 * pad - cs.k + 1;
     }
     static const bool igemm = getenv("ODEVIO_ENC_BWD_IGEMM") != nullptr;   // diagnostic: the fp32-input MFMA form (4 x slower)
+    // 5 x 5 stride-2 blocks (conv2, conv3: two thirds of the input-gradient MACs in the dilated form) on even-sized inputs: four
+    // stride-1 3 x 3 convolutions of the undilated gradient, one per pixel parity, interleaved afterwards (ODEVIO_DGRAD_DILATED: the old form)
+    if (!igemm && p->conv_wTp[i][0] && Hi == 2 * Ho && Wi == 2 * Wo && getenv("ODEVIO_DGRAD_DILATED") == nullptr) {
+      unsigned* amax = reinterpret_cast<unsigned*>(p->enc_dscale + 1024);
+      enc_pack_dilate(D, p->enc_Dd.p, P, Ho, Wo, Ho, Wo, cs.cout, 1, amax, p->enc_dscale, cs.cin, p->conv_wT_inv_prescale[i], st);
+      const size_t Mc = (size_t)P * Ho * Wo;
+      for (int cl = 0; cl < 4; ++cl) {
+        ConvSplitArgs a{};
+        a.in = p->enc_Dd.p; a.w = p->conv_wTp[i][cl]; a.zeros = p->zero_page; a.out = D + (size_t)cl * Mc * cs.cin; a.status = p->status;   // (D itself is packed: free)
+        a.scale = p->enc_dscale; a.shift = p->zero_vec;
+        a.N = P; a.Hi = Ho; a.Wi = Wo; a.Cin = cs.cout; a.Ho = Ho; a.Wo = Wo; a.Cout = cs.cin; a.KH = a.KW = 3; a.stride = 1; a.pad = 1;
+        a.M = (int)Mc; a.slope = 1.0f; a.out_split = 0; a.ld_out = cs.cin; a.terms = 3;
+        a.in_bytes = extent_of(p, a.in, Mc * cs.cout * sizeof(float));
+        a.w_bytes = p->conv_wTp_bytes[i];
+        set_off32(p, a, a.in);
+        a.out_bytes = extent_of(p, a.out, Mc * cs.cin * sizeof(float));
+        const int nkt = 9 * cs.cout / 32;
+        const ConvPlanF plan = plan_f16x2(32 + i, a.M, a.Cout, nkt, p->n_cu, a.off32 != 0);
+        for (int ph = 0; ph < plan.n; ++ph) {
+          const ConvPhase& f = plan.ph[ph];
+          a.wide = f.wide; a.bm = f.bm; a.m_begin = f.m_begin; a.m_end = f.m_end;
+          a.splitk = f.splitk;
+          a.ktiles_per_split = (nkt + a.splitk - 1) / a.splitk;
+          a.splitk = (nkt + a.ktiles_per_split - 1) / a.ktiles_per_split;
+          if (a.splitk > 1) {
+            if ((rc = ensure(p->partial, (size_t)a.splitk * a.M * a.Cout))) return rc;
+            a.partial = p->partial.p;
+            a.partial_bytes = p->partial.n * sizeof(float);
+          }
+          HIPCHK(launch_conv_f16x2(a, st));
+        }
+      }
+      enc_interleave_parity(D, gA, P, Ho, Wo, cs.cin, st);
+      continue;
+    }
     if (!igemm) {
       // the forward's fp16x2 kernel: D scaled by a per-tensor power of two into the two-piece layout (zero-dilated in the same pass), the
       // tap-reversed filter as pieces, an identity epilogue that divides both factors back out, fp32 output

@@ -44,6 +44,9 @@ void enc_dilate(const float* D, float* Dd, int N, int Ho, int Wo, int Hd, int Wd
 // both the filter's pre-scale and e.  amax: one device word of scratch.
 void enc_pack_dilate(const float* D, void* out, int N, int Ho, int Wo, int Hd, int Wd, int C, int stride, unsigned* amax, float* scale, int n_scale,
                      float inv_prescale, hipStream_t st);
+// The four parity classes of a stride-2 block's input gradient (each [N][Ho][Wo][C], class 2 py + px = the pixels (2 i + py, 2 j + px)),
+// src [4][N][Ho][Wo][C], woven into out [N][2 Ho][2 Wo][C].  C % 4 == 0.
+void enc_interleave_parity(const float* src, float* out, int N, int Ho, int Wo, int C, hipStream_t st);
 // img [B][S][3][H][W] -> frame pairs as NHWC with 8 channel slots [B*(S-1)][H][W][8] (conv1's input for the weight gradient; slots 6, 7 zero)
 void enc_pairs_nhwc8(const float* img, float* out, int B, int S, int H, int W, hipStream_t st);
 // visual_head weight gradient from the kernels' (H, W, C) column order back to the reference's flatten order (C, H, W): out[n][c][s] = in[n][s][c]

@@ -417,6 +417,25 @@ void enc_pack_dilate(const float* D, void* out, int N, int Ho, int Wo, int Hd, i
                      Wo, Hd, Wd, C, stride, amax);
   hipLaunchKernelGGL(fill_scale_kernel, dim3((n_scale + 255) / 256), dim3(256), 0, st, scale, n_scale, inv_prescale, amax);
 }
+// out [N][2 Ho][2 Wo][C] <- src [4 classes][N][Ho][Wo][C]: class (py, px) = 2 py + px holds the pixels (2 i + py, 2 j + px)
+__global__ void interleave_parity_kernel(const float* __restrict__ src, float* __restrict__ out, int N, int Ho, int Wo, int C) {
+  const int Q = C >> 2;
+  const size_t per = (size_t)N * Ho * Wo * Q, total = 4 * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % Q);
+    size_t px = i / Q;                       // pixel of the OUTPUT grid, row-major
+    const int x = (int)(px % (2 * Wo));
+    px /= 2 * Wo;
+    const int y = (int)(px % (2 * Ho));
+    const int n = (int)(px / (2 * Ho));
+    const int cl = 2 * (y & 1) + (x & 1);
+    const size_t s = (size_t)cl * per + (((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * Q + c4;
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(src)[s];
+  }
+}
+void enc_interleave_parity(const float* src, float* out, int N, int Ho, int Wo, int C, hipStream_t st) {
+  hipLaunchKernelGGL(interleave_parity_kernel, dim3(ew_blocks((size_t)N * Ho * Wo * C)), dim3(256), 0, st, src, out, N, Ho, Wo, C);
+}
 void enc_pairs_nhwc8(const float* img, float* out, int B, int S, int H, int W, hipStream_t st) {
   hipLaunchKernelGGL(pairs_nhwc8_kernel, dim3(ew_blocks((size_t)B * (S - 1) * H * W)), dim3(256), 0, st, img, out, B, S, H, W);
 }

@@ -243,7 +243,7 @@ def test_train_epoch_follows_torch_with_batchnorm_in_train_mode(optimizer, accum
 
 
 @pytest.mark.parametrize("hw,B,S", [((64, 128), 2, 3), ((96, 160), 1, 3)])
-def test_image_encoder_backward_matches_autograd_through_the_oracle(hw, B, S):
+def test_image_encoder_backward_matches_autograd_through_the_oracle(hw, B, S, monkeypatch):
     """odevio_image_encoder_bwd: every Image_net parameter gradient (nine Conv2d weights, BatchNorm gamma / beta, the visual head)
     against torch.autograd through the oracle's train-mode image encoder in float64, fed the device's dropout masks - Dropout,
     LeakyReLU, batch-statistics BatchNorm backward, weight gradients (contraction over all pixels) and input gradients (stride-1
@@ -272,6 +272,24 @@ def test_image_encoder_backward_matches_autograd_through_the_oracle(hw, B, S):
         worst[n] = float((got.cpu().double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
     bad = {n: e for n, e in worst.items() if e > 1e-3}
     assert not bad, bad
+    # conv2 / conv3's input gradients above ran as four parity sub-convolutions of the undilated gradient; the dilated form and conv1's
+    # unfolded weight gradient (64-wide channel tile per tap) must give the same numbers
+    first = {n: params[n].grad.clone() for n in names}
+    for n in names:
+        params[n].grad = None
+    monkeypatch.setenv("ODEVIO_DGRAD_DILATED", "1")
+    monkeypatch.setenv("ODEVIO_WGRAD_NO_FOLD", "1")
+    model.set_seed(41)
+    fv2 = train.image_encoder(model, img.cuda())
+    (fv2 * wgt.cuda()).sum().backward()
+    model.check()
+    monkeypatch.delenv("ODEVIO_DGRAD_DILATED")
+    monkeypatch.delenv("ODEVIO_WGRAD_NO_FOLD")
+    assert torch.equal(fv, fv2)
+    for n in names:
+        e = float((params[n].grad - first[n]).abs().max() / first[n].abs().max().clamp_min(1e-30))
+        assert e < 5e-5, (n, e)
+    assert any(not torch.equal(params[n].grad, first[n]) for n in names)
     with pytest.raises(ValueError):                                  # a backward needs ITS forward: another shape has nothing kept
         from odevio_amd import _lib
         arr = train._tensor_array(["Image_net.visual_head.bias"], [torch.empty(512, device="cuda")])
