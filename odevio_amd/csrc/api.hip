@@ -113,6 +113,7 @@ struct odevio_plan {
   size_t conv_wTs_bytes[9] = {};
   void* conv_wTp[9][4] = {};               // 5 x 5 stride-2 blocks: the four PARITY sub-filters (3 x 3, one per (row, column) parity of the input pixel)
   size_t conv_wTp_bytes[9] = {};
+  size_t conv_wTq_bytes[9][4] = {};        // 3 x 3 stride-2 blocks: the classes' filters differ in size ((1 + py) x (1 + px))
   float conv_wT_inv_prescale[9] = {};
   float* enc_dscale = nullptr;             // [1024] epilogue scale of the current input-gradient convolution + one word for max|D|
   DevBuf enc_z[9], enc_a[9];
@@ -290,7 +291,7 @@ static int bn_fold(const WeightTable& wt, const std::string& bn, int c, const st
 // x * prescale = h + l, h = fp16(.), l = fp16(. - h) (round to nearest even, subnormals kept).  `prescale` is a power of
 // two that lifts the layer's largest weight to [2^13, 2^14): the low pieces of all but vanishing weights are then normal
 // fp16 numbers, and 1/prescale goes into the BatchNorm scale exactly.
-static float split_conv_weights(const std::vector<float>& w, int cout, int cin, int kk, std::vector<uint16_t>& out) {
+static float split_conv_weights(const std::vector<float>& w, int cout, int cin, int kk, std::vector<uint16_t>& out, float forced_prescale = 0.f) {
   float wmax = 0.f;
   for (float x : w) wmax = std::max(wmax, std::fabs(x));
   int e = 0;
@@ -299,7 +300,7 @@ static float split_conv_weights(const std::vector<float>& w, int cout, int cin, 
     e = 14 - e;                   // wmax * 2^e in [2^13, 2^14)
   }
   e = std::max(-40, std::min(40, e));
-  const float prescale = std::ldexp(1.0f, e);
+  const float prescale = forced_prescale > 0.f ? forced_prescale : std::ldexp(1.0f, e);   // (forced: a part of a filter split with the whole filter's factor)
   const int groups = cin / 32;
   out.assign((size_t)cout * groups * kk * 64, 0);
   for (int n = 0; n < cout; ++n)
@@ -717,6 +718,29 @@ extern "C" int odevio_plan_create(const odevio_config* cfg, const odevio_tensor*
           p->conv_wTp_bytes[i] = per * sizeof(uint16_t);
           for (int cl = 0; cl < 4; ++cl) {
             std::vector<uint16_t> one(wps.begin() + cl * per, wps.begin() + (cl + 1) * per);
+            one.resize(one.size() + ODEVIO_ZERO_PAGE_BYTES / sizeof(uint16_t), 0);
+            TRY(dev_alloc(p, &p->conv_wTp[i][cl], one.size() * sizeof(uint16_t)));
+            HIPCHK(hipMemcpyAsync(p->conv_wTp[i][cl], one.data(), one.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+          }
+        }
+        if (cs.k == 3 && cs.stride == 2) {
+          // the same for the 3 x 3 stride-2 blocks (pad 1): class (py, px) is a (1 + py) x (1 + px) correlation with NO padding whose output
+          // is as large as the gradient (the last row / column sees its second tap hang over the edge = zeros):
+          //   g_x[2i][.] = D[i] W[1];   g_x[2i+1][.] = D[i] W[2] + D[i+1] W[0]          (per dimension) - 9 filter slots per four pixels, not 36
+          for (int cl = 0; cl < 4; ++cl) {
+            const int py = cl >> 1, px = cl & 1, KHc = 1 + py, KWc = 1 + px;
+            std::vector<float> wc((size_t)cs.cin * cs.cout * KHc * KWc);
+            for (int c = 0; c < cs.cin; ++c)
+              for (int n = 0; n < cs.cout; ++n)
+                for (int ty = 0; ty < KHc; ++ty)
+                  for (int tx = 0; tx < KWc; ++tx) {
+                    const int kh = py ? 2 * (1 - ty) : 1, kw = px ? 2 * (1 - tx) : 1;
+                    wc[(((size_t)c * cs.cout + n) * KHc + ty) * KWc + tx] = w[((size_t)n * cs.cin + c) * 9 + kh * 3 + kw];
+                  }
+            std::vector<uint16_t> one;
+            (void)split_conv_weights(wc, cs.cin, cs.cout, KHc * KWc, one, ps);
+            p->conv_wTq_bytes[i][cl] = one.size() * sizeof(uint16_t);
             one.resize(one.size() + ODEVIO_ZERO_PAGE_BYTES / sizeof(uint16_t), 0);
             TRY(dev_alloc(p, &p->conv_wTp[i][cl], one.size() * sizeof(uint16_t)));
             HIPCHK(hipMemcpyAsync(p->conv_wTp[i][cl], one.data(), one.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
@@ -1380,9 +1404,9 @@ static int image_encoder_bwd(odevio_plan* p, const float* img, int B, int S, con
       Wd = Wi + 2 * pad - cs.k + 1;
     }
     static const bool igemm = getenv("ODEVIO_ENC_BWD_IGEMM") != nullptr;   // diagnostic: the fp32-input MFMA form (4 x slower)
-    // 5 x 5 stride-2 blocks (conv2, conv3: two thirds of the input-gradient MACs in the dilated form) on even-sized inputs: four
-    // stride-1 3 x 3 convolutions of the undilated gradient, one per pixel parity, interleaved afterwards (ODEVIO_DGRAD_DILATED: the old form)
-    if (!igemm && p->conv_wTp[i][0] && Hi == 2 * Ho && Wi == 2 * Wo && getenv("ODEVIO_DGRAD_DILATED") == nullptr) {
+    // stride-2 blocks on even-sized inputs: four stride-1 convolutions of the UNdilated gradient, one per pixel parity (3 x 3 with zero
+    // slots for the 5 x 5 blocks, (1 + py) x (1 + px) for the 3 x 3 blocks), interleaved afterwards (ODEVIO_DGRAD_DILATED: the old form)
+    if (!igemm && p->conv_wTp[i][0] && cs.stride == 2 && Hi == 2 * Ho && Wi == 2 * Wo && getenv("ODEVIO_DGRAD_DILATED") == nullptr) {
       unsigned* amax = reinterpret_cast<unsigned*>(p->enc_dscale + 1024);
       enc_pack_dilate(D, p->enc_Dd.p, P, Ho, Wo, Ho, Wo, cs.cout, 1, amax, p->enc_dscale, cs.cin, p->conv_wT_inv_prescale[i], st);
       const size_t Mc = (size_t)P * Ho * Wo;
@@ -1390,13 +1414,14 @@ static int image_encoder_bwd(odevio_plan* p, const float* img, int B, int S, con
         ConvSplitArgs a{};
         a.in = p->enc_Dd.p; a.w = p->conv_wTp[i][cl]; a.zeros = p->zero_page; a.out = D + (size_t)cl * Mc * cs.cin; a.status = p->status;   // (D itself is packed: free)
         a.scale = p->enc_dscale; a.shift = p->zero_vec;
-        a.N = P; a.Hi = Ho; a.Wi = Wo; a.Cin = cs.cout; a.Ho = Ho; a.Wo = Wo; a.Cout = cs.cin; a.KH = a.KW = 3; a.stride = 1; a.pad = 1;
+        a.N = P; a.Hi = Ho; a.Wi = Wo; a.Cin = cs.cout; a.Ho = Ho; a.Wo = Wo; a.Cout = cs.cin; a.stride = 1;
+        if (cs.k == 5) { a.KH = a.KW = 3; a.pad = 1; a.w_bytes = p->conv_wTp_bytes[i]; }                            // 3 x 3, zero slots where a tap falls outside the 5 x 5
+        else { a.KH = 1 + (cl >> 1); a.KW = 1 + (cl & 1); a.pad = 0; a.w_bytes = p->conv_wTq_bytes[i][cl]; }       // 1 x 1, 1 x 2, 2 x 1, 2 x 2
         a.M = (int)Mc; a.slope = 1.0f; a.out_split = 0; a.ld_out = cs.cin; a.terms = 3;
         a.in_bytes = extent_of(p, a.in, Mc * cs.cout * sizeof(float));
-        a.w_bytes = p->conv_wTp_bytes[i];
         set_off32(p, a, a.in);
         a.out_bytes = extent_of(p, a.out, Mc * cs.cin * sizeof(float));
-        const int nkt = 9 * cs.cout / 32;
+        const int nkt = a.KH * a.KW * cs.cout / 32;
         const ConvPlanF plan = plan_f16x2(32 + i, a.M, a.Cout, nkt, p->n_cu, a.off32 != 0);
         for (int ph = 0; ph < plan.n; ++ph) {
           const ConvPhase& f = plan.ph[ph];

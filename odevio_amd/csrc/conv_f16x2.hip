@@ -526,7 +526,11 @@ static bool conv_args_consistent(const ConvSplitArgs& a) {
   if (a.m_begin < 0 || a.m_begin >= a.m_end || a.m_end > a.M) return false;
   if ((a.m_begin != 0 || a.m_end != a.M) && a.splitk > 1) return false;   // the split-K combine runs over the whole layer
   if ((size_t)a.N * a.Ho * a.Wo != (size_t)a.M) return false;
-  if ((a.Hi + 2 * a.pad - a.KH) / a.stride + 1 != a.Ho || (a.Wi + 2 * a.pad - a.KW) / a.stride + 1 != a.Wo) return false;
+  // the usual output size - or, at stride 1, an output as large as the input whose last rows / columns see the filter hang over the
+  // edge (those taps are masked to the zero page like any tap outside the image): the parity classes of a stride-2 input gradient
+  const bool usual = (a.Hi + 2 * a.pad - a.KH) / a.stride + 1 == a.Ho && (a.Wi + 2 * a.pad - a.KW) / a.stride + 1 == a.Wo;
+  const bool same = a.stride == 1 && a.Ho == a.Hi && a.Wo == a.Wi && 2 * a.pad <= a.KH - 1 && 2 * a.pad <= a.KW - 1;
+  if (!usual && !same) return false;
   const size_t nk = (size_t)a.KH * a.KW * (a.Cin / 32);
   if (a.in_bytes < (size_t)a.N * a.Hi * a.Wi * a.Cin * 4) return false;          // P2: 4 bytes per element
   if (a.w_bytes < (size_t)a.Cout * nk * HROW) return false;
