@@ -1343,7 +1343,7 @@ static int image_encoder_bwd(odevio_plan* p, const float* img, int B, int S, con
     if (i > 0) n_dil = std::max(n_dil, (size_t)P * p->conv_h[i] * p->conv_w_sp[i] * cs.cout);   // (dilated to the input's size; stride 1: the same size)
     const int cin_k = i == 0 ? 8 : cs.cin;
     const int M = P * p->conv_h[i + 1] * p->conv_w_sp[i + 1];
-    n_part = std::max(n_part, enc_wgrad_partial_floats(cs.cout, cin_k, cs.k * cs.k, enc_wgrad_pick_splits(M, cs.cout, cin_k, cs.k * cs.k)));
+    n_part = std::max(n_part, enc_wgrad_partial_floats(cs.cout, cin_k, cs.k * cs.k, enc_wgrad_pick_splits(M, cs.cout, cin_k, cs.k * cs.k, p->conv_w_sp[i + 1])));
   }
   n_act = std::max(n_act, (size_t)P * p->conv_h[0] * p->conv_w_sp[0] * 8);   // conv1's frame pairs as NHWC with 8 slots
   n_act = std::max(n_act, (size_t)V * p->head_k);                             // the head's weight gradient before its permutation
@@ -1392,7 +1392,7 @@ static int image_encoder_bwd(odevio_plan* p, const float* img, int B, int S, con
       } else {
         a.x = p->enc_a[i - 1].p; a.x_f32 = 0; a.Cin = cs.cin; a.cin_out = cs.cin;
       }
-      a.splits = enc_wgrad_pick_splits(a.M, a.Cout, a.Cin, cs.k * cs.k);
+      a.splits = enc_wgrad_pick_splits(a.M, a.Cout, a.Cin, cs.k * cs.k, Wo);
       HIPCHK(enc_wgrad(a, st));
     }
     if (i == 0) break;

@@ -33,7 +33,7 @@ struct WgradArgs {
   int fold_kw;         // (set by enc_wgrad) conv1's form: the 64 tile columns are (kw, channel slot) of one filter row
 };
 size_t enc_wgrad_partial_floats(int Cout, int Cin, int taps, int splits);
-int enc_wgrad_pick_splits(int M, int Cout, int Cin, int taps);
+int enc_wgrad_pick_splits(int M, int Cout, int Cin, int taps, int Wo);
 hipError_t enc_wgrad(const WgradArgs& a, hipStream_t st);
 
 // D [N][Ho][Wo][C] -> Dd [N][Hd][Wd][C] with Dd[n][s ho][s wo] = D[n][ho][wo] and zeros elsewhere (the input of the stride-1

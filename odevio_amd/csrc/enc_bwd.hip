@@ -236,6 +236,106 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         if (co < a.Cout && ci < a.Cin && (!fold || (col >> 3) < a.KW)) a.partial[((size_t)split * taps + t) * per + (size_t)co * a.Cin + ci] = acc[i][j][e];
       }
 }
+// The same gradient for the wide layers (Wo a multiple of 32: conv2 .. conv4_1, four fifths of the time): one workgroup = one 64 x 64
+// tile of one filter ROW kh - all KW taps of it - over a range of 32-pixel runs of output rows.  A run's gradient tile D [32][64 co] is
+// staged once and multiplied against KW shifted views of ONE input patch ((32 - 1) s + KW pixels of input row ho s + kh - pad): the
+// per-tap kernel loaded D and a fresh x tile for every tap - 2 KW loads where this one makes 1 + (s + (KW - 1) / 32), and KW x the
+// MFMAs between two barriers.  Accumulators: KW x (2 x 2) tiles per wave.  Same slabs, same reduce kernel.
+#define WR_PX 32
+template <int KW>
+__global__ __launch_bounds__(256) void wgrad_row_kernel(WgradArgs a) {
+  constexpr int NPC_MAX = (WR_PX - 1) * 2 + KW;           // patch pixels at stride 2
+  __shared__ float Dt[WR_PX * WG_LD], Xp[NPC_MAX * WG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int kh = blockIdx.x % a.KH, split = blockIdx.x / a.KH;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int s = a.stride;
+  const int npc = (WR_PX - 1) * s + KW;                   // patch pixels of this layer
+  const int ldx = s == 1 ? WG_LD : 72;                    // patch row stride: lanes q = 0 .. 3 read rows s apart - (s ldx) mod 64 = 16 keeps them on four bank groups
+  f32x4 acc[KW][2][2];
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lrow = tid >> 4, lcol = 4 * (tid & 15);       // loader: pixel lrow + 16 j, four consecutive channels at lcol
+  const bool co_ok = co0 + lcol < a.Cout, ci_ok = ci0 + lcol < a.Cin;
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+  const int G = a.Cin >> 5;
+  const int runs_per_row = a.Wo / WR_PX;
+  const int run_begin = split * a.chunks_per_split, run_end = min((split + 1) * a.chunks_per_split, a.N * a.Ho * runs_per_row);
+  f32x4 dv[WR_PX / 16], xv[(NPC_MAX + 15) / 16];
+  auto fetch = [&](int run) __attribute__((always_inline)) {   // run -> registers (the loads stay in flight under the previous run's MFMAs)
+    const int row = run / runs_per_row, wo0 = (run - row * runs_per_row) * WR_PX;     // row = n * Ho + ho
+    const int n = row / a.Ho, ho = row - n * a.Ho;
+    const int hi = ho * s + kh - a.pad;
+    const int wi0 = wo0 * s - a.pad;
+#pragma unroll
+    for (int j = 0; j < WR_PX / 16; ++j) {
+      const size_t m = (size_t)row * a.Wo + wo0 + lrow + 16 * j;
+      dv[j] = co_ok ? *reinterpret_cast<const f32x4*>(a.D + m * a.Cout + co0 + lcol) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < (NPC_MAX + 15) / 16; ++j) {
+      const int pp = lrow + 16 * j, wi = wi0 + pp;
+      xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pp < npc && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi && ci_ok) {
+        const size_t pi = ((size_t)n * a.Hi + hi) * a.Wi + wi;
+        const int ci = ci0 + lcol;
+        const unsigned char* p = xb + (pi * (size_t)G + (size_t)(ci >> 5)) * 128 + (size_t)(ci & 31) * 2;
+        const h16x4_t h = *reinterpret_cast<const h16x4_t*>(p), l = *reinterpret_cast<const h16x4_t*>(p + 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[j][e] = (float)h[e] + (float)l[e];
+      }
+    }
+  };
+  if (run_begin < run_end) fetch(run_begin);
+  for (int run = run_begin; run < run_end; ++run) {
+    __syncthreads();                                      // every wave is done reading the previous run
+#pragma unroll
+    for (int j = 0; j < WR_PX / 16; ++j) *reinterpret_cast<f32x4*>(&Dt[(lrow + 16 * j) * WG_LD + lcol]) = dv[j];
+#pragma unroll
+    for (int j = 0; j < (NPC_MAX + 15) / 16; ++j)
+      if (lrow + 16 * j < NPC_MAX) *reinterpret_cast<f32x4*>(&Xp[(lrow + 16 * j) * ldx + lcol]) = xv[j];
+    __syncthreads();
+    if (run + 1 < run_end) fetch(run + 1);
+#pragma unroll 2
+    for (int kk = 0; kk < WR_PX / 4; ++kk) {
+      const int px = 4 * kk + q;                          // this lane's pixel of the run (the MFMA's k index)
+      float av[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = Dt[px * WG_LD + wr * 32 + 16 * i + r];
+#pragma unroll
+      for (int t = 0; t < KW; ++t) {
+        const int xrow = (px * s + t) * ldx;
+        float bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = Xp[xrow + wc * 32 + 16 * j + r];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[t][i][j], 0, 0, 0);
+      }
+    }
+  }
+  const int taps = a.KH * a.KW;
+  const size_t per = (size_t)a.Cout * a.Cin;
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = co0 + wr * 32 + 16 * i + 4 * q + e, ci = ci0 + wc * 32 + 16 * j + r;
+          if (co < a.Cout && ci < a.Cin) a.partial[((size_t)split * taps + kh * a.KW + t) * per + (size_t)co * a.Cin + ci] = acc[t][i][j][e];
+        }
+}
+
 // slabs in slab order -> dW [Cout][Cin][KH][KW]
 __global__ void wgrad_reduce_kernel(WgradArgs a) {
   const int taps = a.KH * a.KW;
@@ -375,9 +475,13 @@ size_t enc_wgrad_partial_floats(int Cout, int Cin, int taps, int splits) { retur
 // conv1's shape: the filter row folded into the tile's columns (wgrad_kernel)
 static bool wgrad_folds(int Cin, int KW, int x_f32) { return x_f32 && Cin == 8 && KW * 8 <= 64; }
 
-int enc_wgrad_pick_splits(int M, int Cout, int Cin, int taps) {
+// the layers whose output rows hold whole 32-pixel runs (wgrad_row_kernel)
+static bool wgrad_rowwise(int Wo, int KW, int x_f32, int stride) { return !x_f32 && Wo % WR_PX == 0 && (KW == 3 || KW == 5) && (stride == 1 || stride == 2); }
+
+int enc_wgrad_pick_splits(int M, int Cout, int Cin, int taps, int Wo) {
   long tiles = (long)taps * ((Cout + 63) / 64) * ((Cin + 63) / 64);
   if (Cin == 8 && taps == 49) tiles = 7L * ((Cout + 63) / 64);     // (the folded form launches a workgroup per filter ROW)
+  if (Cin % 32 == 0 && Wo % WR_PX == 0 && (taps == 9 || taps == 25)) tiles /= (taps == 9 ? 3 : 5);   // (so does the row-wise kernel)
   const int chunks = (M + WG_PX - 1) / WG_PX;
   long s = (2048 + tiles - 1) / tiles;            // ~8 workgroups per CU in flight over the launch
   s = std::max(1L, std::min<long>(s, chunks));
@@ -397,6 +501,17 @@ hipError_t enc_wgrad(const WgradArgs& a_in, hipStream_t st) {
   const int taps = a.KH * a.KW;
   a.fold_kw = wgrad_folds(a.Cin, a.KW, a.x_f32) && getenv("ODEVIO_WGRAD_NO_FOLD") == nullptr ? 1 : 0;
   (void)hipGetLastError();
+  if (wgrad_rowwise(a.Wo, a.KW, a.x_f32, a.stride) && getenv("ODEVIO_WGRAD_PER_TAP") == nullptr) {
+    // runs of 32 output pixels instead of chunks: the same split arithmetic over runs
+    const int runs = a.N * a.Ho * (a.Wo / WR_PX);
+    a.chunks_per_split = (runs + a_in.splits - 1) / a_in.splits;
+    a.splits = (runs + a.chunks_per_split - 1) / a.chunks_per_split;
+    const dim3 grid(a.KH * a.splits, (a.Cout + 63) / 64, (a.Cin + 63) / 64);
+    if (a.KW == 3) hipLaunchKernelGGL(wgrad_row_kernel<3>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_row_kernel<5>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_blocks((size_t)a.Cout * a.Cin * taps)), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   if (a.fold_kw)
     hipLaunchKernelGGL(wgrad_kernel, dim3(a.KH * a.splits, (a.Cout + 63) / 64, 1), dim3(256), 0, st, a);
   else

@@ -242,7 +242,7 @@ def test_train_epoch_follows_torch_with_batchnorm_in_train_mode(optimizer, accum
             assert oc.rel_err(now[k], leaves[k]) < 2e-5, k
 
 
-@pytest.mark.parametrize("hw,B,S", [((64, 128), 2, 3), ((96, 160), 1, 3)])
+@pytest.mark.parametrize("hw,B,S", [((64, 128), 2, 3), ((96, 160), 1, 3), ((128, 256), 1, 2)])   # (128 x 256: rows of 64 / 32 pixels - the row-wise weight gradient)
 def test_image_encoder_backward_matches_autograd_through_the_oracle(hw, B, S, monkeypatch):
     """odevio_image_encoder_bwd: every Image_net parameter gradient (nine Conv2d weights, BatchNorm gamma / beta, the visual head)
     against torch.autograd through the oracle's train-mode image encoder in float64, fed the device's dropout masks - Dropout,
@@ -279,12 +279,14 @@ def test_image_encoder_backward_matches_autograd_through_the_oracle(hw, B, S, mo
         params[n].grad = None
     monkeypatch.setenv("ODEVIO_DGRAD_DILATED", "1")
     monkeypatch.setenv("ODEVIO_WGRAD_NO_FOLD", "1")
+    monkeypatch.setenv("ODEVIO_WGRAD_PER_TAP", "1")      # (and the per-tap weight-gradient kernel instead of the row-wise one)
     model.set_seed(41)
     fv2 = train.image_encoder(model, img.cuda())
     (fv2 * wgt.cuda()).sum().backward()
     model.check()
     monkeypatch.delenv("ODEVIO_DGRAD_DILATED")
     monkeypatch.delenv("ODEVIO_WGRAD_NO_FOLD")
+    monkeypatch.delenv("ODEVIO_WGRAD_PER_TAP")
     assert torch.equal(fv, fv2)
     for n in names:
         e = float((params[n].grad - first[n]).abs().max() / first[n].abs().max().clamp_min(1e-30))
