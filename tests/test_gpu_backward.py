@@ -353,6 +353,46 @@ def test_pose_net_trainer_follows_torch_adam_on_the_oracle(cfg, clip):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kind", ["Adam", "SGD"])
+def test_optimizer_step_over_many_tensors_follows_torch(kind):
+    """odevio_optimizer_step (one call, one launch per 64 tensors) against torch.optim over 70 tensors of assorted sizes, two learning
+    rates, weight decay and a clip factor, three steps: parameters and optimizer state."""
+    import ctypes
+    from odevio_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    sizes = [int(x) for x in torch.randint(1, 5000, (70,), generator=g)]
+    ref = [torch.randn(n, generator=g).cuda().requires_grad_(True) for n in sizes]
+    dev = [r.detach().clone() for r in ref]
+    s1 = [torch.zeros_like(p) for p in dev]
+    s2 = [torch.zeros_like(p) for p in dev]
+    lrs_py = [1e-2 if i % 3 else 3e-3 for i in range(len(sizes))]
+    groups = [{"params": [p], "lr": lr} for p, lr in zip(ref, lrs_py)]
+    wd = 1e-3
+    opt = torch.optim.Adam(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd) if kind == "Adam" else torch.optim.SGD(groups, lr=1e-2, momentum=0.9, weight_decay=wd)
+    names = [f"t{i}" for i in range(len(sizes))]
+    coef = torch.tensor([0.0, 0.5], device="cuda")                 # {norm (unused here), clip factor}
+    lrs = (ctypes.c_float * len(sizes))(*lrs_py)
+    for step in range(1, 4):
+        grads = [torch.randn(n, generator=g).cuda() for n in sizes]
+        for r, gr in zip(ref, grads):
+            r.grad = gr * 0.5                                      # torch sees the clipped gradient
+        opt.step()
+        arr = lambda ts: train._tensor_array(names, ts)
+        rc = lib.odevio_optimizer_step(0 if kind == "Adam" else 1, arr(dev), arr(grads), arr(s1), arr(s2) if kind == "Adam" else None, lrs, len(sizes),
+                                       0.9, 0.999, 1e-8, wd, step, coef.data_ptr(), None)
+        _lib.check(rc)
+        torch.cuda.synchronize()
+        for i, (d, r) in enumerate(zip(dev, ref)):
+            assert torch.allclose(d, r.detach(), rtol=2e-6, atol=2e-7), (kind, step, i, float((d - r.detach()).abs().max()))
+    st = opt.state[ref[5]]
+    assert torch.allclose(s1[5], st["exp_avg"] if kind == "Adam" else st["momentum_buffer"], rtol=2e-6, atol=1e-7)
+    # sizes that disagree are refused before anything is written
+    bad = train._tensor_array(names, [torch.empty(3, device="cuda")] * len(sizes))
+    assert lib.odevio_optimizer_step(0, train._tensor_array(names, dev), bad, train._tensor_array(names, s1), train._tensor_array(names, s2), lrs, len(sizes),
+                                     0.9, 0.999, 1e-8, 0.0, 1, None, None) == _lib.ERR_BAD_ARG
+
+
 def test_training_reduces_the_loss_on_a_fixed_batch():
     opt = default_opt(img_h=64, img_w=128, ode_solver="rk4", freeze_encoder=True)
     model, _ = make_model(opt, seed=82)
