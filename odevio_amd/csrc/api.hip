@@ -2080,7 +2080,7 @@ static int fill_train_model(odevio_plan* p, TrainModel& m) {
   for (int l = 0; l <= p->nlin; ++l) m.dims[l] = p->dims_real[l];
   for (int l = 0; l < p->nlin; ++l) m.ode_b[l] = p->ode_b[l];
   m.reg_w0 = p->reg_w0; m.reg_b0 = p->reg_b0; m.reg_w2 = p->reg_w2; m.reg_b2 = p->reg_b2;
-  m.stages = 1; m.jmax = 1; m.adaptive = 0; m.dtlog = nullptr; m.dtcnt = nullptr; m.dtlog_cap = 0; m.ylog = nullptr; m.yend = nullptr; m.adj = nullptr;
+  m.stages = 1; m.jmax = 1; m.adaptive = 0; m.dtlog = nullptr; m.dtcnt = nullptr; m.dtlog_cap = 0; m.ylog = nullptr; m.yend = nullptr; m.adj = nullptr; m.steps_per_interval = nullptr;
   if (m.with_ode) {
     IntegTableau t;
     fill_tableau(c.ode_solver, t);
@@ -2195,6 +2195,7 @@ static int ode_rnn_bwd_impl(odevio_plan* p, const float* fused, const float* ts,
   if (rc) return rc;
   TrainGrads g;
   memset(&g, 0, sizeof(g));
+  std::vector<int> steps_it;   // (outlives the sweep below: TrainModel points into it)
   const int F = p->F;
   for (int i = 0; i < n_grads; ++i) {
     if (!grads[i].name || !grads[i].data) return fail(ODEVIO_ERR_BAD_ARG, "odevio_ode_rnn_bwd: gradient %d has no name / pointer", i);
@@ -2233,6 +2234,7 @@ static int ode_rnn_bwd_impl(odevio_plan* p, const float* fused, const float* ts,
     TapeLayout t = tape_layout(p, B, P, cap);
     StepLog log;
     bool have = false;
+    steps_it.clear();
     if (tape) {
       if ((int64_t)t.total() != tape_floats)
         return fail(ODEVIO_ERR_BAD_ARG, "odevio_ode_rnn_bwd_taped: tape of %lld floats, odevio_ode_rnn_tape_floats says %lld", (long long)tape_floats, (long long)t.total());
@@ -2264,6 +2266,11 @@ static int ode_rnn_bwd_impl(odevio_plan* p, const float* fused, const float* ts,
         continue;
       }
       m.jmax = std::max(1, most);
+      // per interval the most steps any row took: the sweep of an interval starts there (rows are [layer][sequence] x intervals)
+      steps_it.assign(P, 0);
+      for (size_t r = 0; r < (size_t)t.R; ++r)
+        for (int it = 0; it < P; ++it) steps_it[it] = std::max(steps_it[it], cnt[r * P + it]);
+      m.steps_per_interval = steps_it.data();
       break;
     }
     if (want_log) {
@@ -2310,8 +2317,8 @@ extern "C" int odevio_plan_update(odevio_plan* p, const odevio_tensor* weights, 
     if (it->second.second != numel) { rc = fail(ODEVIO_ERR_BAD_ARG, "odevio_plan_update: weight '%s' has the wrong size", name.c_str()); return nullptr; }
     return it->second.first;
   };
-  auto copy = [&](float* dst, const float* s, size_t n) {
-    if (!rc && hipMemcpyAsync(dst, s, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = fail(ODEVIO_ERR_HIP, "odevio_plan_update: copy failed");
+  auto copy = [&](float* dst, const float* s, size_t n) {   // (a kernel, not hipMemcpyAsync: twenty of these per training step)
+    if (!rc) device_copy_f32(dst, s, n, st);
   };
   // first pass: every tensor present with the right size (nothing is written before that is known)
   std::vector<std::pair<std::string, int64_t>> need;

@@ -95,6 +95,7 @@ struct IntegAdjArgs {
   float ta[7][7], tb[7];
   // tape geometry: row of (stage s, interval it, step j, row r) = s * stage_rows + (it * J + j) * Rtot + r
   int J, it, Rtot;
+  int Jrun;                               // steps of THIS interval that any row took (<= J, the tape's stride): the sweep starts there, not at J
   size_t stage_rows;
   const float* tape_act[INTEG_MAX_LIN + 1];   // saved activation OUTPUTS, [l] for l = 1 .. nlin ([nlin] = K, the stage derivative)
   float* tape_delta[INTEG_MAX_LIN];        // [l]: the gradient at the output of Linear l (pre-activation), width dims_io[l+1]

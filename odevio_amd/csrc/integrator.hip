@@ -929,7 +929,7 @@ __global__ __launch_bounds__(INTEG_THREADS) void integrator_adj_kernel(const Int
     return gx;
   };
 
-  for (int j = a.J - 1; j >= 0 && !c.failed; --j) {
+  for (int j = a.Jrun - 1; j >= 0 && !c.failed; --j) {   // (steps Jrun .. J - 1 are zero-length for every row: nothing to sweep)
     const size_t step_row = ((size_t)a.it * a.J + j) * a.Rtot + grow;
     const float dtr = (orow < R && row_valid) ? a.dt[step_row] : 0.f;
     float lk[7];

@@ -35,6 +35,9 @@ struct TrainModel {
   // optional: the launch-independent arguments of the integrator's adjoint twin (integrator.h); with them the reverse sweep of an
   // interval's Runge-Kutta steps is ONE persistent launch instead of one launch per product
   const IntegAdjArgs* adj;
+  // optional (adaptive solvers): per interval the largest number of accepted steps any row took (host array of P ints) - the reverse sweep
+  // of an interval skips the zero-length steps behind it
+  const int* steps_per_interval;
 };
 
 // Where the weight gradients go (device pointers, same shapes as the reference's parameters; null = not wanted).
@@ -78,6 +81,7 @@ int train_optimizer_multi(const OptTable& t, int kind, float b1, float b2, float
 int train_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int step, const float* clip2,
                    hipStream_t st);
 // parameter re-layout on the device (the index maps of odevio_plan_create's host code)
+void device_copy_f32(float* dst, const float* src, size_t n, hipStream_t st);
 void relayout_transpose(const float* src, float* dst, int N, int K, hipStream_t st);
 void relayout_shard(const float* W, float* out, int N, int K, int members, hipStream_t st);
 void relayout_rnn(const float* wih, const float* whh, const float* bih, const float* bhh, float* out_w, float* out_b, int F, int gru, int members,

@@ -858,6 +858,10 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
   gemm_nt(st, dhid, 128, m.reg_w0_t, 128, nullptr, dout, F, (int)MB, F, 128);          // d out = dhid W0
   if (grad_hT) hipLaunchKernelGGL(copy_kernel, EW_GRID(RF), 0, st, grad_hT, lam, RF);
   else (void)hipMemsetAsync(lam, 0, RF * sizeof(float), st);
+  // (steps the sweep skips - zero-length for every row of their interval - still have rows in the tape, and the weight gradients sum
+  //  over ALL rows: their pre-activation gradients must read as the zeros the sweep would have written)
+  if (m.with_ode && m.adj && m.steps_per_interval)
+    for (int l = 0; l < nl; ++l) (void)hipMemsetAsync(delta[l], 0, M * m.dims[l + 1] * sizeof(float), st);
   for (int it = P - 1; it >= 0; --it) {
     // lam = dL/d(state after the RNN of interval it); the top layer's output also feeds the regressor (dout) and, below the top,
     // the layer above sent a gradient down its input (dinp): both enter the cell's backward as its second gradient
@@ -881,6 +885,8 @@ int train_ode_rnn_bwd(const TrainModel& m, float* ws, const float* fused, const 
       // all J steps of the interval, every stage and layer, in one launch per chunk of rows (integrator_adj_kernel)
       IntegAdjArgs a = *m.adj;
       a.J = J; a.it = it; a.Rtot = R; a.stage_rows = PJR;
+      a.Jrun = m.steps_per_interval ? std::max(0, std::min(J, m.steps_per_interval[it])) : J;
+      if (a.Jrun == 0) continue;
       for (int l = 1; l <= nl; ++l) a.tape_act[l] = act[l];
       for (int l = 0; l < nl; ++l) a.tape_delta[l] = delta[l];
       a.dt = dt; a.lam = lam;
@@ -1196,6 +1202,8 @@ __global__ void rnn_bias_kernel(const float* __restrict__ bih, const float* __re
     vb[i] = x;
   }
 }
+// a device-to-device copy as a kernel: hipMemcpyAsync's copy-engine path costs ~14 us of stream time per call, whatever the size
+void device_copy_f32(float* dst, const float* src, size_t n, hipStream_t st) { hipLaunchKernelGGL(copy_kernel, EW_GRID(n), 0, st, src, dst, n); }
 void relayout_transpose(const float* src, float* dst, int N, int K, hipStream_t st) {
   hipLaunchKernelGGL(transpose_kernel, EW_GRID((size_t)N * K), 0, st, src, dst, N, K);
 }
