@@ -2068,7 +2068,7 @@ extern "C" int odevio_cde_bwd(odevio_plan* p, const float* obs, int32_t B, int32
 // backward (train.hip)
 static int fill_train_model(odevio_plan* p, TrainModel& m) {
   const odevio_config& c = p->cfg;
-  if (c.model_type == ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "backward: the Neural-CDE path has no backward yet");
+  if (c.model_type == ODEVIO_MODEL_CDE) return fail(ODEVIO_ERR_UNSUPPORTED, "odevio_ode_rnn_bwd: Neural-CDE plans take odevio_cde_bwd");
   // (the tape runs on plain GEMMs over the REAL widths - only the persistent forward kernel pads them - and needs whole float4 rows)
   if (p->F % 4 || (c.model_type == ODEVIO_MODEL_ODE_RNN && c.ode_hidden_dim % 4))
     return fail(ODEVIO_ERR_UNSUPPORTED, "backward: v_f_len+i_f_len (%d) and ode_hidden_dim (%d) must be multiples of 4", p->F, c.ode_hidden_dim);

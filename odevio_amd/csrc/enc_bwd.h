@@ -1,9 +1,10 @@
 // Backward of the image encoder under model.train() (enc_bwd.hip): what loss.backward() does to the nine conv blocks of the
 // reference's ImageEncoder (src/models/Encoder.py:8-22,82-90,116-122) when --freeze_encoder is off (scripts/train_model.py:78,84:
-// Image_net's gradients then count in clip_grad_norm_).  Correctness-first, all fp32:
+// Image_net's gradients then count in clip_grad_norm_):
 //   per block, last first:  g_a (grad of the block's output) -> Dropout / LeakyReLU / batch-statistics BatchNorm backward -> D = grad
 //   of the bare convolution z -> weight gradient (enc_wgrad: contraction over every pixel of the batch on the fp32 MFMA) and input
-//   gradient (a stride-1 convolution of the zero-dilated D with the flipped filter on conv_igemm_kernel, api.hip).
+//   gradient (api.hip: D packed into the forward's two-fp16-piece layout with a per-tensor power-of-two scale and convolved on the
+//   forward's fp16x2 kernel - stride-2 blocks as four parity classes of the undilated gradient, woven together by enc_interleave_parity).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

@@ -1,24 +1,26 @@
-// Backward of the ODE-RNN pose path (first slice of SURVEY.md section 8f-3): gradients of a loss on the poses through
-// the regressor, the nn.RNN stack and the Runge-Kutta solve of every interval, down to the fused features, the
-// carried hidden state and every weight of ODEFunc / RNN / regressor - what `loss.backward()` reaches below the
-// encoders in the reference's training step (scripts/train_model.py:69-78: poses -> 100 * MSE(angles) + MSE(trans) ->
-// autograd through torchode's AutoDiffAdjoint = backpropagation through the solver's own operations).
+// Backward of the ODE-RNN pose path: gradients of a loss on the poses through the regressor, the
+// nn.RNN / nn.GRU stack and the Runge-Kutta solve of every interval, down to the fused features, the carried hidden state and
+// every weight of ODEFunc / RNN / regressor - what `loss.backward()` reaches below the encoders in the reference's training
+// step (scripts/train_model.py:69-78: poses -> 100 * MSE(angles) + MSE(trans) -> autograd through torchode's AutoDiffAdjoint
+// = backpropagation through the solver's own operations).  Also here: the skinny fp32-MFMA products every backward of the
+// library uses, the fusion / inertial-encoder backwards, the loss, gradient clipping and the optimizer step.
 //
-// Discretise-then-optimise: the backward differentiates exactly the arithmetic the forward performs (same tableau,
-// same steps), so the gradients are the gradients of the computed poses, not of the continuous ODE.
+// Discretise-then-optimise: the backward differentiates exactly the arithmetic the forward performs (same tableau, same
+// steps), so the gradients are the gradients of the computed poses, not of the continuous ODE.
 //
-// Structure (correctness first; the forward's persistent kernel has no backward twin yet):
-//   1. TAPE: the forward is recomputed with plain launches (skinny MFMA GEMMs + element-wise kernels), writing every
-//      layer input / output of every stage evaluation into row-stacked matrices act[l] [M, dims[l]] with
-//      M = intervals x sub-steps x stages x rows, and the RNN cell inputs / outputs per layer;
-//   2. REVERSE SWEEP interval by interval: RNN cell backward, then the adjoint of every RK step (stage by stage, last
-//      to first), writing the pre-activation gradients into delta[l] [M, dims[l+1]];
-//   3. WEIGHT GRADIENTS as ONE GEMM per weight: dW_l = delta[l]^T act[l] (contraction over all M rows at once: the
-//      rank-R updates of a step-by-step formulation become a single [N, M] x [M, K] product), biases = column sums.
-// Supported now: fixed-step solvers (rk4 = 3/8 rule, rk4_classic; any ode_substeps) and the adaptive ones (dopri5, tsit5,
-// heun: the forward's ACCEPTED steps are replayed from the integrator's log, their sizes treated as constants of the
-// differentiation), tanh nn.RNN and nn.GRU, every ODEFunc activation; fusion is the caller's (the gradient is returned
-// w.r.t. the FUSED features).
+// Structure:
+//   1. TAPE: every layer input / output of every stage of every step in row-stacked matrices act[l] [M, dims[l]],
+//      M = stages x intervals x steps x rows, and the RNN cell inputs / outputs per layer.  With the forward's log (the state every
+//      accepted step starts from, IntegArgs::ylog / yend) all steps are rebuilt in ONE batch per stage and layer; without it
+//      the steps are walked in order from the recomputed states;
+//   2. REVERSE SWEEP interval by interval: RNN cell backward (launches), then the adjoint of the interval's RK steps - one launch
+//      of integrator_adj_kernel (integrator.hip: the persistent forward kernel's twin on W^T) or, where that is unavailable, one
+//      launch per product - writing the pre-activation gradients into delta[l] [M, dims[l+1]];
+//   3. WEIGHT GRADIENTS as ONE product per weight: dW_l = delta[l]^T act[l] (contraction over all M rows at once), the bias
+//      gradient from the same launch.
+// Solvers: fixed-step (rk4 = 3/8 rule, rk4_classic; any ode_substeps) and adaptive (dopri5, tsit5, heun, euler under torchode's
+// controller: the forward's ACCEPTED steps are replayed from the log, their sizes treated as constants of the
+// differentiation); tanh nn.RNN and nn.GRU; every ODEFunc activation; the gradient is returned w.r.t. the FUSED features.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -367,9 +367,11 @@ class PoseNetTrainer:
     The reference builds ``torch.optim.Adam(betas=(0.9, 0.999), eps=1e-8, weight_decay=args.weight_decay)`` over
     ``Pose_net``'s parameters only, and per batch runs forward -> ``100 * MSE(angles) + MSE(translations)`` ->
     ``backward`` -> ``clip_grad_norm_(max_norm=args.gradient_clip)`` -> ``optimizer.step()`` -> ``zero_grad()``.  Here every
-    one of those stages is a libodevio call; PyTorch carries the graph between them.  ``step`` takes the encoder FEATURES
-    (``model.image_encoder`` / ``model.imu_encoder`` outputs, eval-mode BatchNorm - the encoders' train-mode forward and
-    their backward are not built, and their parameters are not the optimizer's).
+    one of those stages is a libodevio call; PyTorch carries the graph between them.  ``step`` / ``accumulate`` take the encoder
+    FEATURES, or the raw ``imu`` / ``img`` - then the encoders are part of the graph (train-mode BatchNorm and Dropout when the model is
+    in ``train()``; ``Image_net`` only when ``freeze_encoder`` is off): their gradients count in the clipping norm as in the
+    reference, whose optimizer nevertheless never holds them.  The optimizer step itself is ONE call over all tensors
+    (``odevio_optimizer_step``), the plan's copies of the parameters are refreshed in place (``odevio_plan_update``).
     """
 
     def __init__(self, model, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, gradient_clip=None, process_group=None,
